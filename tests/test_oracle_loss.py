@@ -1,0 +1,74 @@
+"""Pins for the CPU restatement of the RNN-T loss (oracle/rnnt_loss_ref.c) — SURVEY.md §8(c) G3-G5.
+
+The reference has no test at this boundary and its loss packages are not installable offline, so these
+pins are: upstream known-answer vector, brute force, autograd through an independent DP, invariants.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.rnnt_oracle import rnnt_loss_c, rnnt_nll_bruteforce, rnnt_nll_torch
+
+G3_LOGITS = np.array([[[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.6, 0.1, 0.1], [0.1, 0.1, 0.2, 0.8, 0.1]],
+                      [[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.2, 0.1, 0.1], [0.7, 0.1, 0.2, 0.1, 0.1]]])[None]
+G3_GRAD = np.array([[[-0.13116688, -0.3999269, 0.17703125, 0.17703125, 0.17703125],
+                     [-0.18572757, 0.12247056, -0.18168412, 0.12247056, 0.12247056],
+                     [-0.32091254, 0.06269141, 0.06928472, 0.12624499, 0.06269141]],
+                    [[0.05456069, -0.21824276, 0.05456069, 0.05456069, 0.05456069],
+                     [0.12073959, 0.12073959, -0.48295835, 0.12073959, 0.12073959],
+                     [-0.6925882, 0.16871116, 0.18645467, 0.16871116, 0.16871116]]])[None]
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 2e-7), (np.float32, 5e-7)])
+def test_g3_known_answer(dtype, tol):
+    nll, grad = rnnt_loss_c(G3_LOGITS.astype(dtype), np.array([[1, 2]]), [2], [2], blank=0)
+    assert abs(float(nll[0]) - 4.495666) < 2e-6
+    np.testing.assert_allclose(grad, G3_GRAD, atol=tol)
+
+
+@pytest.mark.parametrize("T,U,V,seed", [(1, 0, 3, 0), (1, 3, 4, 1), (4, 0, 5, 2), (2, 2, 5, 3), (5, 4, 6, 4), (3, 3, 2, 5)])
+def test_g4_bruteforce(T, U, V, seed):
+    rng = np.random.default_rng(seed)
+    z = rng.normal(size=(1, T, U + 1, V)) * 2.0
+    y = rng.integers(1, V, size=(1, max(U, 1)))[:, :U].reshape(1, U)
+    blank = 0
+    nll, _ = rnnt_loss_c(z, y, [T], [U], blank)
+    assert abs(nll[0] - rnnt_nll_bruteforce(z[0], list(y[0]), blank)) < 1e-10
+
+
+def test_autograd_through_dp_ragged_and_nonzero_blank():
+    rng = np.random.default_rng(7)
+    B, T, U, V, blank = 3, 6, 4, 7, 2
+    z = rng.normal(size=(B, T, U + 1, V))
+    y = rng.integers(0, V - 1, size=(B, U))
+    y[y >= blank] += 1  # labels never equal blank
+    t_lens, u_lens = [6, 4, 1], [4, 0, 3]
+    nll, grad = rnnt_loss_c(z, y, t_lens, u_lens, blank)
+    zt = torch.tensor(z, requires_grad=True)
+    ref = rnnt_nll_torch(zt, y.tolist(), t_lens, u_lens, blank)
+    ref.sum().backward()
+    np.testing.assert_allclose(nll, ref.detach().numpy(), atol=1e-12)
+    np.testing.assert_allclose(grad, zt.grad.numpy(), atol=1e-12)
+    # G5 invariants: zero outside the valid lattice, softmax-fused grads sum to zero over V
+    for b in range(B):
+        assert np.all(grad[b, t_lens[b]:] == 0) and np.all(grad[b, :, u_lens[b] + 1:] == 0)
+    np.testing.assert_allclose(grad.sum(-1), 0, atol=1e-12)
+
+
+def test_f32_tracks_f64_on_long_lattice():
+    rng = np.random.default_rng(3)
+    z = rng.normal(size=(2, 300, 21, 72))
+    y = rng.integers(1, 72, size=(2, 20))
+    n64, g64 = rnnt_loss_c(z, y, [300, 250], [20, 11])
+    n32, g32 = rnnt_loss_c(z.astype(np.float32), y, [300, 250], [20, 11])
+    assert np.max(np.abs(n32 - n64) / n64) < 2e-6
+    # alpha/beta reach |1e3| here, so one fp32 ulp in log space is ~6e-5: grads agree to ~1e-3 only
+    assert np.max(np.abs(g32 - g64)) < 2e-3
+
+
+def test_bad_lengths_rejected():
+    z = np.zeros((1, 3, 2, 4))
+    with pytest.raises(ValueError):
+        rnnt_loss_c(z, np.array([[1]]), [4], [1])
+    with pytest.raises(ValueError):
+        rnnt_loss_c(z, np.array([[1]]), [3], [2])
