@@ -1,0 +1,170 @@
+/*
+ * rnnt_hip.h — C ABI of librnnt_hip.so: the MI355X (gfx950) native RNN-Transducer training hot path.
+ *
+ * The reference (YooSungHyun/RNNTransducer) has NO native code and therefore no FFI of its own
+ * (SURVEY.md §0, §2b): every kernel it runs comes from a dependency.  This header declares the entry
+ * points a maintainer would bind in place of those dependency calls; each one cites the reference call
+ * site it replaces (paths relative to the reference repo).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions:
+ *   - plain `extern "C"`, raw device pointers + explicit dims, `void* stream` is a hipStream_t;
+ *   - return 0 on success, <0 on error; rnnt_hip_last_error() gives a thread-local message;
+ *   - the CALLER owns all memory incl. workspaces (sizes from *_workspace_bytes); the library never
+ *     allocates or frees device memory, never synchronises the device, keeps no global mutable state;
+ *   - all float tensors are fp32, all lengths/labels int32, token ids int64 (dataloader.py:21-24,28-36);
+ *   - "time-major" = (T,B,F) contiguous; "batch-major" = (B,T,F) contiguous.
+ */
+#ifndef RNNT_HIP_H_
+#define RNNT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNNT_HIP_ABI_VERSION 1
+
+#define RNNT_OK 0
+#define RNNT_ERR_INVALID (-1)   /* bad argument (dims, alignment, null pointer)            */
+#define RNNT_ERR_LAUNCH (-2)    /* hip launch / runtime error                              */
+#define RNNT_ERR_UNSUPPORTED (-3) /* configuration outside what the kernels handle         */
+#define RNNT_ERR_TIMEOUT (-4)   /* a persistent kernel gave up on an inter-CU wait         */
+
+int rnnt_hip_version(void);
+const char* rnnt_hip_last_error(void);
+/* number of compute units the persistent LSTM kernels size their grid against (0 = no device) */
+int rnnt_hip_device_cus(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense fp32 GEMM on f32-input MFMA (v_mfma_f32_32x32x2_f32):  C = op(A) . op(B) (+ bias)
+ * Replaces the BLAS calls behind nn.Linear / the hoisted LSTM input projection:
+ *   networks/encoder.py:76,103 (out_proj), networks/decoder.py:80,124 (out_proj),
+ *   networks/transducer.py:39,69 (fc), and the W_ih.x_t half of nn.LSTM (encoder.py:67-75,99).
+ *
+ *   A(m,k) = A[rowoff_a(m) + k*a_sk]            if a_mc == 0   (k-contiguous rows, a_sk must be 1)
+ *   A(m,k) = A[k*a_sk + m]                      if a_mc == 1   (m-contiguous, "transposed" operand)
+ *     rowoff_a(m) = a_rowidx ? a_rowidx[m]*a_si : (m / a_div)*a_so + (m % a_div)*a_si
+ *   B(k,n) = B[n*b_sn + k*b_sk]                 exactly one of b_sn, b_sk is 1
+ *   C(m,n) = C[(m / c_div)*c_so + (m % c_div)*c_si + n]
+ * flags: see RNNT_GEMM_*.
+ * ---------------------------------------------------------------------------------------------- */
+#define RNNT_GEMM_GELU_A 1u      /* apply gelu_tanh to A elements on load  (transducer.py:38,68)   */
+#define RNNT_GEMM_GELU_B 2u      /* apply gelu_tanh to B elements on load                          */
+#define RNNT_GEMM_ACCUM 4u       /* C += result                                                    */
+#define RNNT_GEMM_MUL_DGELU 8u   /* C = result * gelu_tanh'(aux(m,n)), aux laid out like C          */
+
+typedef struct rnnt_gemm_desc {
+  int64_t M, N, K;
+  const float* A;
+  int64_t a_div, a_so, a_si, a_sk;
+  int32_t a_mc;
+  const int64_t* a_rowidx;
+  const float* B;
+  int64_t b_sn, b_sk;
+  float* C;
+  int64_t c_div, c_so, c_si;
+  const float* bias; /* (N) or NULL */
+  const float* aux;  /* for RNNT_GEMM_MUL_DGELU */
+  uint32_t flags;
+} rnnt_gemm_desc;
+
+int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LSTM layer (both directions in one launch), packed-sequence semantics.
+ * Replaces torch.nn.LSTM over a PackedSequence + sort/pack/unpack/unsort:
+ *   networks/encoder.py:67-75 (ctor), :93-102 (forward);  networks/decoder.py:71-79, :105-120.
+ *
+ * Layouts: x (T,B,I) time-major [or any (x_st, x_sb) element strides], y (T,B,D*H) time-major.
+ *   Frames t >= lens[b] produce y == 0 and contribute no gradient (pad_packed_sequence semantics,
+ *   encoder.py:101); the reverse direction starts at each sequence's own last valid frame.
+ *   Weights in torch layout: w_ih[d] (4H,I), w_hh[d] (4H,H), b_ih[d], b_hh[d] (4H), gate order i,f,g,o.
+ *   Requirements: H % 4 == 0, D in {1,2}, B <= 64 per call, T >= 1.
+ *
+ * Stash written by fwd and consumed by bwd (caller-owned, sizes below):
+ *   gates: D*T*B*4H floats ... activated gates, overwritten with dG by bwd
+ *   cst  : D*T*B*H  floats ... cell states
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rnnt_lstm_desc {
+  int32_t T, B, I, H, D;
+  const int32_t* lens; /* (B) device */
+  const float* x;
+  int64_t x_st, x_sb; /* element strides of x over t and b (feature stride 1) */
+  const float* w_ih[2];
+  const float* w_hh[2];
+  const float* b_ih[2];
+  const float* b_hh[2];
+  float* y;       /* (T,B,D*H) */
+  float* y_drop;  /* (T,B,D*H) y with inter-layer dropout applied, or NULL when dropout_p == 0 */
+  float dropout_p;
+  uint64_t dropout_seed;
+  float* gates;   /* (T,B,D*4H) permuted gate layout, see DESIGN.md */
+  float* cst;     /* (D,T,H/4,B,4) */
+  void* workspace;
+  size_t workspace_bytes;
+} rnnt_lstm_desc;
+
+size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D);
+int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream);
+
+typedef struct rnnt_lstm_bwd_desc {
+  rnnt_lstm_desc f;   /* same description as the forward call (x, weights, y, stash, workspace) */
+  const float* dy;    /* (T,B,D*H) gradient w.r.t. y (w.r.t. y_drop when dropout_p > 0) */
+  float* dx;          /* (T,B,I) time-major, or NULL (first layer: dataloader.py gives no grad to mel) */
+  float* dw_ih[2];    /* (4H,I)  written (not accumulated) */
+  float* dw_hh[2];    /* (4H,H) */
+  float* db[2];       /* (4H)   gradient of b_ih == gradient of b_hh */
+} rnnt_lstm_bwd_desc;
+
+int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* d, void* stream);
+/* reads back the persistent kernels' status word from a workspace (synchronises `stream`);
+ * 0 = ok, RNNT_ERR_TIMEOUT if an inter-CU wait gave up.  For tests and the bench, not for hot loops. */
+int rnnt_hip_lstm_check(const void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused joint + log-softmax + RNN-T lattice (never materialises (B,T,U+1,V) nor (B,T,U+1,2*O)).
+ * Replaces JointNet.joint (networks/transducer.py:54-69) followed by RNNTLoss (model.py:39,57):
+ *   z[b,t,u,:] = fc(gelu_tanh(cat(enc[b,t], dec[b,u]))) = A[b,t,:] + C[b,u,:] + bias     
+ * Inputs here are the two small pre-GEMM results A = gelu(enc).W_e^T, C = gelu(dec).W_d^T (computed with
+ * rnnt_hip_gemm_f32 + RNNT_GEMM_GELU_A) and fc.bias (V).  A(b,t,v) = A[b*a_sb + t*a_st + v],
+ * C(b,u,v) = C[b*c_sb + u*c_su + v]  (so batch-major and time-major buffers both work, no copy).
+ * Outputs: nll (B) = -log P(y|x) per utterance; dA, dC (same strides as A, C) = d(sum_b gscale*nll_b)/dA,dC.
+ *   labels (B,U) int32 (U = U1-1), t_lens (B) int32 in [1,T], u_lens (B) int32 in [0,U].
+ * ---------------------------------------------------------------------------------------------- */
+size_t rnnt_hip_joint_loss_workspace_bytes(int32_t B, int32_t T, int32_t U1, int32_t V);
+int rnnt_hip_joint_loss_fwd_bwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,
+                                const float* bias, const int32_t* labels, const int32_t* t_lens,
+                                const int32_t* u_lens, int32_t B, int32_t T, int32_t U1, int32_t V, int32_t blank,
+                                float gscale, float* nll, float* dA, float* dC, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
+/* Materialising joint for RNNTransducer.forward() (model.py:47-50): logits (B,T,U1,V) = A + C + bias. */
+int rnnt_hip_joint_logits_fwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,
+                              const float* bias, int32_t B, int32_t T, int32_t U1, int32_t V, float* logits,
+                              void* stream);
+
+/* warp-transducer-shaped entry (model.py:39,57): loss + gradient from dense logits (B,T,U1,V).
+ * grad may be NULL (forward only).  grad = d(sum_b gscale*nll_b)/d logits. */
+int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int32_t* labels, const int32_t* t_lens,
+                                      const int32_t* u_lens, int32_t B, int32_t T, int32_t U1, int32_t V,
+                                      int32_t blank, float gscale, float* nll, float* grad, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+
+/* Embedding forward (networks/decoder.py:69,102): out[m,:] = W[idx[m],:]  (row padding_idx of W is zero by
+ * construction, nn.Embedding(padding_idx=blank)). */
+int rnnt_hip_embedding_fwd(const float* W, const int64_t* idx, int64_t M, int32_t H, int32_t V, float* out, void* stream);
+
+/* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients: fc.bias, out_proj.bias, LSTM biases) */
+int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream);
+
+/* Embedding backward (networks/decoder.py:69,102): dW[idx[m]] += dE[m] for idx[m] != padding_idx. dW (V,H)
+ * must be zeroed by the caller. */
+int rnnt_hip_embedding_bwd(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V, int64_t padding_idx,
+                           float* dW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNNT_HIP_H_ */

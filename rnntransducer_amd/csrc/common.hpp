@@ -1,0 +1,56 @@
+// Shared helpers for librnnt_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rnnt_hip.h"
+
+namespace rnnt {
+
+void set_error(const char* fmt, ...);
+
+#define RNNT_CHECK_ARG(cond, ...)      \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::rnnt::set_error(__VA_ARGS__);  \
+      return RNNT_ERR_INVALID;         \
+    }                                  \
+  } while (0)
+
+#define RNNT_CHECK_HIP(expr)                                                          \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      ::rnnt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RNNT_ERR_LAUNCH;                                                         \
+    }                                                                                 \
+  } while (0)
+
+#define RNNT_CHECK_LAUNCH() RNNT_CHECK_HIP(hipGetLastError())
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// gelu_tanh and its derivative (torch.nn.GELU(approximate="tanh"), networks/transducer.py:38)
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float dgelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float u = k0 * (x + k1 * x * x2);
+  float th = tanhf(u);
+  float du = k0 * (1.0f + 3.0f * k1 * x2);
+  return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * du;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+}  // namespace rnnt

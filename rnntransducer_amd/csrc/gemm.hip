@@ -1,0 +1,275 @@
+// fp32 GEMM on the f32-input matrix cores of gfx950 (v_mfma_f32_32x32x2_f32; exact fp32 fma chains).
+//
+// Replaces the BLAS calls behind nn.Linear (networks/encoder.py:76,103; networks/decoder.py:80,124;
+// networks/transducer.py:39,69) and the hoisted W_ih.x_t input projection of nn.LSTM
+// (networks/encoder.py:67-75,99), plus their backward GEMMs.  See include/rnnt_hip.h for operand maps.
+//
+// Tile: 128x128x16 per 256-thread workgroup (4 waves, one per SIMD, 64x64 per wave = 2x2 MFMA tiles),
+// operands staged K-major in LDS (row stride 132 floats: ds_read_b32 of 32 consecutive m/n is
+// conflict-free, ds_write_b128 stays 16-B aligned), register-prefetch double buffering.
+#include "common.hpp"
+
+namespace rnnt {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+
+struct GemmK {
+  int M, N, K;
+  const float* A;
+  int a_div;
+  long a_so, a_si, a_sk;
+  const long* a_rowidx;
+  const float* B;
+  long b_sn, b_sk;
+  float* C;
+  int c_div;
+  long c_so, c_si;
+  const float* bias;
+  const float* aux;
+  unsigned flags;
+};
+
+// Loads this thread's share (2 x 4 floats) of a (128 rows) x (16 k) operand tile and parks it in LDS K-major.
+// KC: operand rows are k-contiguous in memory (row r at rowptr[r], element k at +k).
+// !KC: operand is r-contiguous (element (r,k) at base + k*sk + r).
+template <bool KC, bool VEC4>
+struct TileIO {
+  f32x4 v[2];
+  // KC state
+  const float* rowptr[2];
+  // !KC state
+  const float* base;
+  long sk;
+  int r0, R, K;
+  bool gelu;
+
+  __device__ __forceinline__ void load(int k0) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (KC) {
+        const int k = k0 + 4 * (tid & 3);
+        const float* src = rowptr[p];
+        if (src != nullptr) {
+          if (VEC4 && k + 3 < K) {
+            x = *reinterpret_cast<const f32x4*>(src + k);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k + e < K) x[e] = src[k + e];
+          }
+        }
+      } else {
+        const int k = k0 + (tid >> 5) + 8 * p;
+        const int r = r0 + 4 * (tid & 31);
+        if (k < K) {
+          const float* src = base + (long)k * sk + r;
+          if (VEC4 && r + 3 < R) {
+            x = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (r + e < R) x[e] = src[e];
+          }
+        }
+      }
+      if (gelu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = gelu_tanh(x[e]);
+      }
+      v[p] = x;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* S) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if constexpr (KC) {
+        const int rl = (tid >> 2) + 64 * p;
+        const int kq = 4 * (tid & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[(kq + e) * LDT + rl] = v[p][e];
+      } else {
+        const int kl = (tid >> 5) + 8 * p;
+        *reinterpret_cast<f32x4*>(&S[kl * LDT + 4 * (tid & 31)]) = v[p];
+      }
+    }
+  }
+};
+
+template <bool A_KC, bool B_KC, bool VEC4>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // tile coordinates: consecutive block ids walk down M first so that the (usually small) B panel and a
+  // band of A stay in the XCD's L2; ids are dealt round-robin over 8 XCDs, so regroup them (bijective map).
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
+
+  TileIO<A_KC, VEC4> ta;
+  TileIO<B_KC, VEC4> tb;
+  ta.K = tb.K = p.K;
+  ta.gelu = (p.flags & RNNT_GEMM_GELU_A) != 0;
+  tb.gelu = (p.flags & RNNT_GEMM_GELU_B) != 0;
+  if constexpr (A_KC) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int m = m0 + (tid >> 2) + 64 * q;
+      if (m < p.M) {
+        long off = p.a_rowidx ? p.a_rowidx[m] * p.a_si : (long)(m / p.a_div) * p.a_so + (long)(m % p.a_div) * p.a_si;
+        ta.rowptr[q] = p.A + off;
+      } else {
+        ta.rowptr[q] = nullptr;
+      }
+    }
+  } else {
+    ta.base = p.A;
+    ta.sk = p.a_sk;
+    ta.r0 = m0;
+    ta.R = p.M;
+  }
+  if constexpr (B_KC) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = n0 + (tid >> 2) + 64 * q;
+      tb.rowptr[q] = n < p.N ? p.B + (long)n * p.b_sn : nullptr;
+    }
+  } else {
+    tb.base = p.B;
+    tb.sk = p.b_sk;
+    tb.r0 = n0;
+    tb.R = p.N;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  ta.load(0);
+  tb.load(0);
+  ta.store(As[0]);
+  tb.store(Bs[0]);
+  __syncthreads();
+
+  const int aoff = (lane >> 5) * LDT + wm * 64 + (lane & 31);
+  const int boff = (lane >> 5) * LDT + wn * 64 + (lane & 31);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      ta.load((kt + 1) * BK);
+      tb.load((kt + 1) * BK);
+    }
+    const float* as = As[cur] + aoff;
+    const float* bs = Bs[cur] + boff;
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      const float a0 = as[2 * kp * LDT], a1 = as[2 * kp * LDT + 32];
+      const float b0 = bs[2 * kp * LDT], b1 = bs[2 * kp * LDT + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      ta.store(As[cur ^ 1]);
+      tb.store(Bs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+  const bool accum = (p.flags & RNNT_GEMM_ACCUM) != 0, dgelu = (p.flags & RNNT_GEMM_MUL_DGELU) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+      if (m >= p.M) continue;
+      const long rowoff = (long)(m / p.c_div) * p.c_so + (long)(m % p.c_div) * p.c_si;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        float val = acc[i][j][v];
+        if (p.bias) val += p.bias[n];
+        const long off = rowoff + n;
+        if (dgelu) val *= dgelu_tanh(p.aux[off]);
+        if (accum) val += p.C[off];
+        p.C[off] = val;
+      }
+    }
+  }
+}
+
+inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
+
+}  // namespace
+
+}  // namespace rnnt
+
+extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
+  using namespace rnnt;
+  RNNT_CHECK_ARG(d != nullptr, "gemm: null descriptor");
+  RNNT_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "gemm: negative dims");
+  RNNT_CHECK_ARG(d->M < (1ll << 31) && d->N < (1ll << 31) && d->K < (1ll << 31), "gemm: dims must fit int32");
+  if (d->M == 0 || d->N == 0) return RNNT_OK;
+  RNNT_CHECK_ARG(d->A && d->B && d->C, "gemm: null operand");
+  RNNT_CHECK_ARG(d->c_div >= 1, "gemm: c_div must be >= 1");
+  RNNT_CHECK_ARG(!(d->flags & RNNT_GEMM_MUL_DGELU) || d->aux, "gemm: MUL_DGELU needs aux");
+  const bool b_kc = d->b_sk == 1;
+  RNNT_CHECK_ARG(b_kc || d->b_sn == 1, "gemm: B must be contiguous along k or along n");
+  const bool a_kc = d->a_mc == 0;
+  if (a_kc) {
+    RNNT_CHECK_ARG(d->a_sk == 1, "gemm: k-contiguous A needs a_sk == 1");
+    RNNT_CHECK_ARG(d->a_rowidx || d->a_div >= 1, "gemm: a_div must be >= 1");
+  } else {
+    RNNT_CHECK_ARG(d->a_rowidx == nullptr, "gemm: a_rowidx only with k-contiguous A");
+  }
+
+  GemmK k;
+  k.M = (int)d->M; k.N = (int)d->N; k.K = (int)d->K;
+  k.A = d->A; k.a_div = (int)(d->a_div < 1 ? 1 : (d->a_div > 0x7fffffff ? 0x7fffffff : d->a_div));
+  k.a_so = d->a_so; k.a_si = d->a_si; k.a_sk = d->a_sk; k.a_rowidx = (const long*)d->a_rowidx;
+  k.B = d->B; k.b_sn = d->b_sn; k.b_sk = d->b_sk;
+  k.C = d->C; k.c_div = (int)(d->c_div > 0x7fffffff ? 0x7fffffff : d->c_div); k.c_so = d->c_so; k.c_si = d->c_si;
+  k.bias = d->bias; k.aux = d->aux; k.flags = d->flags;
+
+  bool vec = aligned16(d->A) && aligned16(d->B);
+  if (a_kc) vec = vec && (d->a_si % 4 == 0) && (d->a_rowidx || d->a_so % 4 == 0);
+  else vec = vec && (d->a_sk % 4 == 0);
+  if (b_kc) vec = vec && (d->b_sn % 4 == 0);
+  else vec = vec && (d->b_sk % 4 == 0);
+
+  const int tiles = (int)(ceil_div(d->M, BM) * ceil_div(d->N, BN));
+  dim3 grid(tiles), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(AK, BKC, V) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, V>), grid, block, 0, s, k)
+  if (a_kc && b_kc) { if (vec) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+  else if (a_kc && !b_kc) { if (vec) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+  else if (!a_kc && b_kc) { if (vec) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+  else { if (vec) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+#undef LAUNCH
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}

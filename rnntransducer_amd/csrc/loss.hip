@@ -1,0 +1,531 @@
+// Fused joint + log-softmax + RNN-T lattice for gfx950.
+//
+// Replaces JointNet.joint (networks/transducer.py:54-69: repeat/cat/GELU/Linear materialising
+// (B,T,U+1,2*O) three times and (B,T,U+1,V) once) followed by RNNTLoss(blank, reduction="mean")
+// (model.py:39,57; arithmetic in third-party warp-transducer / torchaudio).  Uses the separable form
+// z[b,t,u,:] = A[b,t,:] + C[b,u,:] + bias so only two floats per lattice cell are ever
+// written: log p(blank) and log p(y_u).
+//
+// Kernels (all HBM/latency-bound integer+transcendental work; no MFMA here by design):
+//   lse_sep_kernel / lse_dense_kernel : per-cell log-sum-exp -> blk[b][u][t], emit[b][u][t] (u-major)
+//   alphabeta_kernel<K>               : one wavefront per (utterance, alpha|beta); lane l owns label
+//                                       positions [l*K, l*K+K) and sweeps t with a one-lane skew, so each
+//                                       step advances one anti-diagonal; neighbour hand-off by lane shuffle;
+//                                       accumulators in fp64 with an fp32 log1p(exp(.)) correction term
+//   grad_sep_kernel                   : dA[b,t,:] = sum_u dz, partial dC slabs per 32-frame tile (LDS adds)
+//   reduce_dc_kernel                  : fixed-order sum of the slabs (bitwise reproducible, no float atomics)
+//   grad_dense_kernel                 : warp-transducer-shaped d/d logits for rnnt_hip_loss_from_logits_*
+#include "common.hpp"
+
+namespace rnnt {
+namespace {
+
+constexpr int TT = 32;  // frames per workgroup tile
+constexpr double NEG_INF = -__builtin_huge_val();
+
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+  return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-cell log-sum-exp, separable logits.  grid (ceil(T/32), ceil(U1/8), B), 256 threads = 32 t x 8 u
+// ------------------------------------------------------------------------------------------------
+constexpr int LSE_UT = 8, LSE_VC = 128;
+
+__global__ void __launch_bounds__(256) lse_sep_kernel(const float* __restrict__ A, const float* __restrict__ C,
+                                                      const float* __restrict__ bias, const int* __restrict__ labels,
+                                                      int T, int U1, int V, int blank, long a_sb, long a_st,
+                                                      long c_sb, long c_su, float* __restrict__ blk,
+                                                      float* __restrict__ emit) {
+  __shared__ float As[TT][LSE_VC + 1];
+  __shared__ float Cs[LSE_UT][LSE_VC + 1];
+  const int b = blockIdx.z, t0 = blockIdx.x * TT, u0 = blockIdx.y * LSE_UT;
+  const int tid = threadIdx.x, tl = tid & 31, ul = tid >> 5;
+  const int t = t0 + tl, u = u0 + ul;
+  const float* Ab = A + (long)b * a_sb;
+  const float* Cb = C + (long)b * c_sb;
+
+  float m = -__builtin_huge_valf(), s = 0.f;
+  for (int v0 = 0; v0 < V; v0 += LSE_VC) {
+    const int vc = min(LSE_VC, V - v0);
+    __syncthreads();
+    for (int i = tid; i < TT * LSE_VC; i += 256) {
+      const int r = i / LSE_VC, c = i % LSE_VC;
+      As[r][c] = (t0 + r < T && c < vc) ? Ab[(long)(t0 + r) * a_st + v0 + c] : 0.f;
+    }
+    for (int i = tid; i < LSE_UT * LSE_VC; i += 256) {
+      const int r = i / LSE_VC, c = i % LSE_VC;
+      Cs[r][c] = (u0 + r < U1 && c < vc) ? Cb[(long)(u0 + r) * c_su + v0 + c] + bias[v0 + c] : 0.f;
+    }
+    __syncthreads();
+    float cm = -__builtin_huge_valf();
+    for (int c = 0; c < vc; ++c) cm = fmaxf(cm, As[tl][c] + Cs[ul][c]);
+    const float nm = fmaxf(m, cm);
+    float cs = 0.f;
+    for (int c = 0; c < vc; ++c) cs += expf(As[tl][c] + Cs[ul][c] - nm);
+    s = s * expf(m - nm) + cs;
+    m = nm;
+  }
+  if (t < T && u < U1) {
+    const float lse = m + logf(s);
+    const long o = ((long)b * U1 + u) * T + t;
+    const float zb = Ab[(long)t * a_st + blank] + Cb[(long)u * c_su + blank] + bias[blank];
+    blk[o] = zb - lse;
+    float e = 0.f;
+    if (u < U1 - 1) {
+      const int y = labels[(long)b * (U1 - 1) + u];
+      e = Ab[(long)t * a_st + y] + Cb[(long)u * c_su + y] + bias[y] - lse;
+    }
+    emit[o] = e;
+  }
+}
+
+// dense logits (B,T,U1,V): one wavefront per cell, lanes along v, grid-stride over cells
+__global__ void __launch_bounds__(256) lse_dense_kernel(const float* __restrict__ Z, const int* __restrict__ labels,
+                                                        int B, int T, int U1, int V, int blank,
+                                                        float* __restrict__ blk, float* __restrict__ emit) {
+  const int lane = threadIdx.x & 63;
+  const long ncell = (long)B * T * U1;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long cell = wave0; cell < ncell; cell += nw) {
+    const float* z = Z + cell * V;
+    float m = -__builtin_huge_valf();
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, z[v]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(z[v] - m);
+    s = wave_sum(s);
+    if (lane == 0) {
+      const int u = (int)(cell % U1);
+      const long bt = cell / U1;
+      const int t = (int)(bt % T), b = (int)(bt / T);
+      const float lse = m + logf(s);
+      const long o = ((long)b * U1 + u) * T + t;
+      blk[o] = z[blank] - lse;
+      emit[o] = (u < U1 - 1) ? z[labels[(long)b * (U1 - 1) + u]] - lse : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// alpha / beta: one wavefront per (b, which).  fp64 accumulation, fp32 correction term.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double logaddexp_d(double a, double b) {
+  const double m = fmax(a, b);
+  if (m == NEG_INF) return NEG_INF;
+  const float d = (float)(fmin(a, b) - m);  // <= 0, -inf allowed
+  return m + (double)log1pf(expf(d));
+}
+__device__ __forceinline__ double shfl_up1(double x, int lane) {
+  double y = __shfl_up(x, 1);
+  return lane == 0 ? NEG_INF : y;
+}
+__device__ __forceinline__ double shfl_down1(double x, int lane) {
+  double y = __shfl_down(x, 1);
+  return lane == 63 ? NEG_INF : y;
+}
+
+template <int K>
+__global__ void __launch_bounds__(64) alphabeta_kernel(const float* __restrict__ blk, const float* __restrict__ emit,
+                                                       const int* __restrict__ t_lens, const int* __restrict__ u_lens,
+                                                       int T, int U1, double* __restrict__ alpha,
+                                                       double* __restrict__ beta, double* __restrict__ ll) {
+  const int b = blockIdx.x, which = blockIdx.y, lane = threadIdx.x;
+  const int Tb = t_lens[b], Ub = u_lens[b];  // valid cells: t < Tb, u <= Ub
+  const long rowbase = (long)b * U1 * T;
+  const int ulo = lane * K;
+  const int lastlane = Ub / K;
+  const int nsteps = Tb + lastlane;
+
+  if (which == 0) {
+    double down[K];  // alpha[t-1][u] + blk[t-1][u]
+#pragma unroll
+    for (int k = 0; k < K; ++k) down[k] = NEG_INF;
+    double eout = NEG_INF;  // alpha[t][uhi] + emit[t][uhi] of this lane's last cell at its current row
+    float pb[K], pe[K];
+    // prefetch row t = 0 - lane (only lane 0 valid at n = 0)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int u = ulo + k, t = 0 - lane;
+      const bool ok = (t >= 0 && t < Tb && u <= Ub);
+      pb[k] = ok ? blk[rowbase + (long)u * T + t] : 0.f;
+      pe[k] = ok ? emit[rowbase + (long)u * T + t] : 0.f;
+    }
+    for (int n = 0; n < nsteps; ++n) {
+      const int t = n - lane;
+      const double carry = shfl_up1(eout, lane);
+      float cb[K], ce[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { cb[k] = pb[k]; ce[k] = pe[k]; }
+      // prefetch next row
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int u = ulo + k, tn = t + 1;
+        const bool ok = (tn >= 0 && tn < Tb && u <= Ub);
+        pb[k] = ok ? blk[rowbase + (long)u * T + tn] : 0.f;
+        pe[k] = ok ? emit[rowbase + (long)u * T + tn] : 0.f;
+      }
+      if (t >= 0 && t < Tb) {
+        double left = carry;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int u = ulo + k;
+          if (u <= Ub) {
+            const double a = (t == 0 && u == 0) ? 0.0 : logaddexp_d(down[k], left);
+            alpha[rowbase + (long)u * T + t] = a;
+            down[k] = a + (double)cb[k];
+            left = (u < Ub) ? a + (double)ce[k] : NEG_INF;
+            if (t == Tb - 1 && u == Ub) ll[b] = down[k];
+          }
+        }
+        eout = left;
+      }
+    }
+  } else {
+    double down[K];  // beta[t+1][u]
+#pragma unroll
+    for (int k = 0; k < K; ++k) down[k] = NEG_INF;
+    double bout = NEG_INF;  // beta[t][ulo] of this lane's first cell at its current row
+    float pb[K], pe[K];
+    // lane l at step n handles t = Tb-1 - (n - (lastlane - l)); lanes > lastlane own no valid cell
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int u = ulo + k, t = Tb - 1 + (lastlane - lane);
+      const bool ok = (t >= 0 && t < Tb && u <= Ub);
+      pb[k] = ok ? blk[rowbase + (long)u * T + t] : 0.f;
+      pe[k] = ok ? emit[rowbase + (long)u * T + t] : 0.f;
+    }
+    for (int n = 0; n < nsteps; ++n) {
+      const int t = Tb - 1 - (n - (lastlane - lane));
+      const double carry = shfl_down1(bout, lane);  // beta[t][(lane+1)*K]
+      float cb[K], ce[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { cb[k] = pb[k]; ce[k] = pe[k]; }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int u = ulo + k, tn = t - 1;
+        const bool ok = (tn >= 0 && tn < Tb && u <= Ub);
+        pb[k] = ok ? blk[rowbase + (long)u * T + tn] : 0.f;
+        pe[k] = ok ? emit[rowbase + (long)u * T + tn] : 0.f;
+      }
+      if (t >= 0 && t < Tb && lane <= lastlane) {
+        double right = carry;  // beta[t][u+1]
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+          const int u = ulo + k;
+          if (u <= Ub) {
+            double v;
+            if (t == Tb - 1 && u == Ub) {
+              v = (double)cb[k];
+            } else {
+              const double ne = down[k] == NEG_INF ? NEG_INF : down[k] + (double)cb[k];
+              const double em = (u < Ub && right != NEG_INF) ? right + (double)ce[k] : NEG_INF;
+              v = logaddexp_d(ne, em);
+            }
+            beta[rowbase + (long)u * T + t] = v;
+            down[k] = v;
+            right = v;
+            if (t == 0 && u == 0) ll[gridDim.x + b] = v;
+          }
+        }
+        bout = right;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-cell scalars for the gradient: occupancy w, row lse, blank- and label-transition posteriors
+// ------------------------------------------------------------------------------------------------
+struct CellS {
+  float w, lse, cb, ce;
+};
+
+__device__ __forceinline__ CellS cell_scalars(const float* __restrict__ blk, const float* __restrict__ emit,
+                                              const double* __restrict__ alpha, const double* __restrict__ beta,
+                                              long rowbase, int T, int t, int u, int Tb, int Ub, double logZ,
+                                              float zblank) {
+  CellS c;
+  const long o = rowbase + (long)u * T + t;
+  const double a = alpha[o], bt = beta[o];
+  const float lb = blk[o];
+  c.w = expf((float)(a + bt - logZ));
+  c.lse = zblank - lb;
+  double tb;
+  if (t == Tb - 1) tb = (u == Ub) ? a + (double)lb - logZ : NEG_INF;
+  else tb = a + (double)lb + beta[o + 1] - logZ;
+  c.cb = expf((float)tb);
+  c.ce = (u < Ub) ? expf((float)(a + (double)emit[o] + beta[o + T] - logZ)) : 0.f;
+  return c;
+}
+
+// grid (ceil(T/32), B), 256 threads; wave w owns frames w, w+4, ... of the tile; lanes run along v.
+// dynamic LDS: cells[TT][U1] (CellS) | Cs[U1][64] | dCs[U1][64] | ys[U1]
+__global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__ A, const float* __restrict__ C,
+                                                       const float* __restrict__ bias, const int* __restrict__ labels,
+                                                       const int* __restrict__ t_lens, const int* __restrict__ u_lens,
+                                                       const float* __restrict__ blk, const float* __restrict__ emit,
+                                                       const double* __restrict__ alpha, const double* __restrict__ beta,
+                                                       const double* __restrict__ ll, int T, int U1, int V, int blank,
+                                                       long a_sb, long a_st, long c_sb, long c_su, float gscale,
+                                                       float* __restrict__ dA, float* __restrict__ dCp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CellS* cells = reinterpret_cast<CellS*>(smem);
+  float* Cs = reinterpret_cast<float*>(cells + TT * U1);
+  float* dCs = Cs + U1 * 64;
+  int* ys = reinterpret_cast<int*>(dCs + U1 * 64);
+
+  const int b = blockIdx.y, tile = blockIdx.x, t0 = tile * TT, ntiles = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Tb = t_lens[b], Ub = u_lens[b];
+  const long rowbase = (long)b * U1 * T;
+  const double logZ = ll[b];
+  const float* Ab = A + (long)b * a_sb;
+  const float* Cb = C + (long)b * c_sb;
+  float* dCtile = dCp + ((long)b * ntiles + tile) * U1 * V;
+
+  for (int i = tid; i < U1; i += 256) ys[i] = (i < U1 - 1) ? labels[(long)b * (U1 - 1) + i] : -1;
+  for (int i = tid; i < TT * U1; i += 256) {
+    const int tl = i / U1, u = i % U1, t = t0 + tl;
+    CellS c = {0.f, 0.f, 0.f, 0.f};
+    if (t < Tb && u <= Ub) {
+      const float zb = Ab[(long)t * a_st + blank] + Cb[(long)u * c_su + blank] + bias[blank];
+      c = cell_scalars(blk, emit, alpha, beta, rowbase, T, t, u, Tb, Ub, logZ, zb);
+    }
+    cells[i] = c;
+  }
+
+  for (int v0 = 0; v0 < V; v0 += 64) {
+    const int v = v0 + lane;
+    const bool vok = v < V;
+    __syncthreads();  // cells/ys ready (first pass); previous chunk's dCs flushed (later passes)
+    for (int i = tid; i < U1 * 64; i += 256) {
+      const int u = i >> 6, c = i & 63;
+      Cs[i] = (v0 + c < V) ? Cb[(long)u * c_su + v0 + c] + bias[v0 + c] : 0.f;
+      dCs[i] = 0.f;
+    }
+    __syncthreads();
+    for (int tl = wave; tl < TT; tl += 4) {
+      const int t = t0 + tl;
+      if (t >= T) break;
+      float acc = 0.f;
+      if (t < Tb && vok) {
+        const float a = Ab[(long)t * a_st + v];
+        for (int u = 0; u <= Ub; ++u) {
+          const CellS c = cells[tl * U1 + u];
+          float g = c.w * expf(a + Cs[u * 64 + lane] - c.lse);
+          if (v == blank) g -= c.cb;
+          if (v == ys[u]) g -= c.ce;
+          acc += g;
+          atomicAdd(&dCs[u * 64 + lane], g);
+        }
+      }
+      if (vok) dA[(long)b * a_sb + (long)t * a_st + v] = acc * gscale;
+    }
+    __syncthreads();
+    for (int i = tid; i < U1 * 64; i += 256) {
+      const int u = i >> 6, c = i & 63;
+      if (v0 + c < V) dCtile[(long)u * V + v0 + c] = dCs[i];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) reduce_dc_kernel(const float* __restrict__ dCp, int ntiles, long per_b, int V,
+                                                        long c_sb, long c_su, float gscale, float* __restrict__ dC) {
+  const int b = blockIdx.y;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per_b) return;
+  const float* src = dCp + (long)b * ntiles * per_b + i;
+  float s = 0.f;
+  for (int k = 0; k < ntiles; ++k) s += src[(long)k * per_b];
+  dC[(long)b * c_sb + (i / V) * c_su + (i % V)] = s * gscale;
+}
+
+// dense d/d logits: one wavefront per cell
+__global__ void __launch_bounds__(256) grad_dense_kernel(const float* __restrict__ Z, const int* __restrict__ labels,
+                                                         const int* __restrict__ t_lens, const int* __restrict__ u_lens,
+                                                         const float* __restrict__ blk, const float* __restrict__ emit,
+                                                         const double* __restrict__ alpha, const double* __restrict__ beta,
+                                                         const double* __restrict__ ll, int B, int T, int U1, int V,
+                                                         int blank, float gscale, float* __restrict__ G) {
+  const int lane = threadIdx.x & 63;
+  const long ncell = (long)B * T * U1;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long cell = wave0; cell < ncell; cell += nw) {
+    const int u = (int)(cell % U1);
+    const long bt = cell / U1;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const int Tb = t_lens[b], Ub = u_lens[b];
+    const float* z = Z + cell * V;
+    float* g = G + cell * V;
+    if (t >= Tb || u > Ub) {
+      for (int v = lane; v < V; v += 64) g[v] = 0.f;
+      continue;
+    }
+    const CellS c = cell_scalars(blk, emit, alpha, beta, (long)b * U1 * T, T, t, u, Tb, Ub, ll[b], z[blank]);
+    const int y = (u < U1 - 1) ? labels[(long)b * (U1 - 1) + u] : -1;
+    for (int v = lane; v < V; v += 64) {
+      float x = c.w * expf(z[v] - c.lse);
+      if (v == blank) x -= c.cb;
+      if (v == y && u < Ub) x -= c.ce;
+      g[v] = x * gscale;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) joint_logits_kernel(const float* __restrict__ A, const float* __restrict__ C,
+                                                           const float* __restrict__ bias, int T, int U1, int V,
+                                                           long a_sb, long a_st, long c_sb, long c_su, long total,
+                                                           float* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % V);
+    long r = i / V;
+    const int u = (int)(r % U1);
+    r /= U1;  // r = b*T + t
+    const long b = r / T, t = r % T;
+    out[i] = A[b * a_sb + t * a_st + v] + C[b * c_sb + u * c_su + v] + bias[v];
+  }
+}
+
+__global__ void nll_kernel(const double* __restrict__ ll, int B, float* __restrict__ nll) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) nll[b] = (float)(-ll[b]);
+}
+
+struct LossWs {
+  float *blk, *emit;
+  double *alpha, *beta, *ll;
+  float* dCp;
+  size_t total;
+};
+
+LossWs carve(void* ws, int B, int T, int U1, int V, bool with_slabs) {
+  LossWs w;
+  const size_t cells = (size_t)B * T * U1;
+  char* p = reinterpret_cast<char*>(ws);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off += align_up(bytes, 256); return q; };
+  w.alpha = reinterpret_cast<double*>(take(cells * 8));
+  w.beta = reinterpret_cast<double*>(take(cells * 8));
+  w.ll = reinterpret_cast<double*>(take((size_t)B * 2 * 8));
+  w.blk = reinterpret_cast<float*>(take(cells * 4));
+  w.emit = reinterpret_cast<float*>(take(cells * 4));
+  const size_t ntiles = ceil_div(T, TT);
+  w.dCp = reinterpret_cast<float*>(take(with_slabs ? (size_t)B * ntiles * U1 * V * 4 : 0));
+  w.total = off;
+  return w;
+}
+
+int check_common(const void* labels, const void* t_lens, const void* u_lens, int B, int T, int U1, int V, int blank,
+                 const void* nll) {
+  RNNT_CHECK_ARG(B >= 1 && T >= 1 && U1 >= 1 && V >= 1, "rnnt loss: dims must be positive (B=%d T=%d U1=%d V=%d)", B, T, U1, V);
+  RNNT_CHECK_ARG(blank >= 0 && blank < V, "rnnt loss: blank %d outside [0,%d)", blank, V);
+  RNNT_CHECK_ARG(U1 <= 64 * 8, "rnnt loss: U+1 = %d exceeds the 512 label positions one wavefront sweeps", U1);
+  RNNT_CHECK_ARG(t_lens && u_lens && nll, "rnnt loss: null lengths/output");
+  RNNT_CHECK_ARG(U1 == 1 || labels, "rnnt loss: null labels");
+  return RNNT_OK;
+}
+
+int launch_alphabeta(const LossWs& w, const int* t_lens, const int* u_lens, int B, int T, int U1, hipStream_t s) {
+  const int K = (int)ceil_div(U1, 64);
+  dim3 grid(B, 2), block(64);
+#define AB(KK) hipLaunchKernelGGL((alphabeta_kernel<KK>), grid, block, 0, s, w.blk, w.emit, t_lens, u_lens, T, U1, w.alpha, w.beta, w.ll)
+  switch (K) {
+    case 1: AB(1); break;
+    case 2: AB(2); break;
+    case 3: AB(3); break;
+    case 4: AB(4); break;
+    default: AB(8); break;
+  }
+#undef AB
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+}  // namespace
+}  // namespace rnnt
+
+using namespace rnnt;
+
+extern "C" size_t rnnt_hip_joint_loss_workspace_bytes(int32_t B, int32_t T, int32_t U1, int32_t V) {
+  if (B < 1 || T < 1 || U1 < 1 || V < 1) return 0;
+  return carve(nullptr, B, T, U1, V, true).total;
+}
+
+extern "C" int rnnt_hip_joint_loss_fwd_bwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb,
+                                           int64_t c_su, const float* bias, const int32_t* labels,
+                                           const int32_t* t_lens, const int32_t* u_lens, int32_t B, int32_t T,
+                                           int32_t U1, int32_t V, int32_t blank, float gscale, float* nll, float* dA,
+                                           float* dC, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_common(labels, t_lens, u_lens, B, T, U1, V, blank, nll)) return rc;
+  RNNT_CHECK_ARG(A && C && bias, "joint_loss: null A/C/bias");
+  RNNT_CHECK_ARG((dA == nullptr) == (dC == nullptr), "joint_loss: dA and dC must both be given or both be NULL");
+  const LossWs w = carve(workspace, B, T, U1, V, true);
+  RNNT_CHECK_ARG(workspace && workspace_bytes >= w.total, "joint_loss: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream;
+  const int ntiles = (int)ceil_div(T, TT);
+
+  hipLaunchKernelGGL(lse_sep_kernel, dim3(ntiles, (unsigned)ceil_div(U1, LSE_UT), B), dim3(256), 0, s, A, C, bias, labels,
+                     T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, w.blk, w.emit);
+  RNNT_CHECK_LAUNCH();
+  if (int rc = launch_alphabeta(w, t_lens, u_lens, B, T, U1, s)) return rc;
+  hipLaunchKernelGGL(nll_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, w.ll, B, nll);
+  RNNT_CHECK_LAUNCH();
+  if (dA) {
+    const size_t lds = (size_t)TT * U1 * sizeof(CellS) + (size_t)U1 * 64 * 4 * 2 + (size_t)U1 * 4;
+    RNNT_CHECK_ARG(lds <= 160 * 1024, "joint_loss: U+1 = %d needs %zu B of LDS (> 160 KiB)", U1, lds);
+    if (lds > 64 * 1024)
+      RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)grad_sep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(grad_sep_kernel, dim3(ntiles, B), dim3(256), lds, s, A, C, bias, labels, t_lens, u_lens, w.blk,
+                       w.emit, w.alpha, w.beta, w.ll, T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, gscale, dA, w.dCp);
+    RNNT_CHECK_LAUNCH();
+    const long per_b = (long)U1 * V;
+    hipLaunchKernelGGL(reduce_dc_kernel, dim3((unsigned)ceil_div(per_b, 256), B), dim3(256), 0, s, w.dCp, ntiles, per_b,
+                       V, (long)c_sb, (long)c_su, gscale, dC);
+    RNNT_CHECK_LAUNCH();
+  }
+  return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_joint_logits_fwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb,
+                                         int64_t c_su, const float* bias, int32_t B, int32_t T, int32_t U1, int32_t V,
+                                         float* logits, void* stream) {
+  RNNT_CHECK_ARG(A && C && bias && logits, "joint_logits: null pointer");
+  RNNT_CHECK_ARG(B >= 1 && T >= 1 && U1 >= 1 && V >= 1, "joint_logits: dims must be positive");
+  const long total = (long)B * T * U1 * V;
+  const unsigned grid = (unsigned)(ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536);
+  hipLaunchKernelGGL(joint_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, C, bias, T, U1, V, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, total, logits);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int32_t* labels, const int32_t* t_lens,
+                                                 const int32_t* u_lens, int32_t B, int32_t T, int32_t U1, int32_t V,
+                                                 int32_t blank, float gscale, float* nll, float* grad, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  if (int rc = check_common(labels, t_lens, u_lens, B, T, U1, V, blank, nll)) return rc;
+  RNNT_CHECK_ARG(logits, "loss_from_logits: null logits");
+  const LossWs w = carve(workspace, B, T, U1, V, true);
+  RNNT_CHECK_ARG(workspace && workspace_bytes >= w.total, "loss_from_logits: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream;
+  const long ncell = (long)B * T * U1;
+  const unsigned grid = (unsigned)(ceil_div(ncell, 4) < 16384 ? ceil_div(ncell, 4) : 16384);
+  hipLaunchKernelGGL(lse_dense_kernel, dim3(grid), dim3(256), 0, s, logits, labels, B, T, U1, V, blank, w.blk, w.emit);
+  RNNT_CHECK_LAUNCH();
+  if (int rc = launch_alphabeta(w, t_lens, u_lens, B, T, U1, s)) return rc;
+  hipLaunchKernelGGL(nll_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, w.ll, B, nll);
+  RNNT_CHECK_LAUNCH();
+  if (grad) {
+    hipLaunchKernelGGL(grad_dense_kernel, dim3(grid), dim3(256), 0, s, logits, labels, t_lens, u_lens, w.blk, w.emit,
+                       w.alpha, w.beta, w.ll, B, T, U1, V, blank, gscale, grad);
+    RNNT_CHECK_LAUNCH();
+  }
+  return RNNT_OK;
+}

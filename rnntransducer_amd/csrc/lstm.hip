@@ -1,0 +1,768 @@
+// Persistent, length-aware LSTM layer for gfx950: both directions of one layer in ONE launch.
+//
+// Replaces torch.nn.LSTM over a PackedSequence plus the sort/pack/unpack/unsort around it
+// (networks/encoder.py:67-75,93-102; networks/decoder.py:71-79,105-120).
+//
+// Decomposition:
+//   * the input projection X.W_ih^T + b_ih + b_hh for ALL timesteps is hoisted into one MFMA GEMM
+//     (gemm.hip) that writes gate pre-activations time-major with the 4 gates of a hidden unit adjacent:
+//     gates[t][b][d][4*j + g];
+//   * the recurrence runs in one persistent kernel: direction d, hidden slice [j0, j0+Hs) per workgroup
+//     (Hs = 4/8/16 units -> D*H/Hs workgroups, one per CU).  The workgroup keeps its 4*Hs rows of W_hh
+//     in LDS for the whole sequence, its cell state in registers, and at every step
+//       1. waits for the per-workgroup step flags of its direction (sc1 polls, bounded spin),
+//       2. gathers h_{t-1} (B x H, write-through exchange buffer, sc1 16-B loads), split-K over the 4 waves,
+//          v_mfma_f32_16x16x4_f32 (rows = gate rows, cols = batch),
+//       3. reduces the 4 partial tiles through LDS, applies the gate non-linearities, masks t >= len[b],
+//       4. writes activated gates (in place of the pre-activations), c_t, y_t and its slice of h_t
+//          (sc1 16-B stores), drains, and publishes flag = step+1.
+//   * backward mirrors it with dG (B x 4H) as the exchanged vector and v_mfma_f32_4x4x1_16B_f32
+//     (16 k-blocks per instruction, so the 4-unit slice wastes no matrix lanes).
+//   Packed-sequence semantics need no sort: a row is simply masked while t >= len[b]; its state stays 0,
+//   so the reverse direction starts from zero at each sequence's own last frame and padded outputs are 0.
+//
+// Inter-workgroup protocol: MI355X_MICROARCH "Valid forms" row 1 — every exchanged byte is stored sc1 by
+// its owner, every storing wave drains vmcnt(0), workgroup barrier, ONE lane publishes an sc1 flag; the
+// consumer polls with sc1 loads from one wave, joins a workgroup barrier, then every wave reads the bytes
+// with sc1 loads.  No dispatch-order or XCD-placement assumption; all spins are bounded (status word).
+#include "common.hpp"
+
+namespace rnnt {
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned long long SPIN_LIMIT_TICKS = 400000000ull;  // 4 s of the 100 MHz s_memrealtime clock
+constexpr int RSRC_FLAGS = 0x00027000;                           // gfx9 raw buffer: 32-bit elements
+constexpr int AUX_SC1 = 16;
+
+struct LstmK {
+  int T, B, H, D, Hs, NC, Bp, LDW;
+  const int* lens;
+  float* gates;   // (T,B,D,4H) gate-adjacent layout
+  float* cst;     // (D,T,H/4,B,4)
+  float* y;       // (T,B,D,H)
+  float* ydrop;   // or nullptr
+  float keep_scale;
+  unsigned drop_thresh;
+  unsigned long long seed;
+  const float* w_hh[2];
+  float* hx;       // fwd: [2][D][H/4][Bp][4]   bwd: [2][D][H][Bp][4]
+  unsigned* flags; // [D][NC]
+  unsigned* status;
+  const float* dy; // bwd: (T,B,D,H)
+};
+
+__device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (unsigned)(z >> 32);
+}
+
+// Wave 0 polls this direction's step flags until all are >= need; everyone then joins a barrier.
+// Returns false (uniformly) if the wait was abandoned (timeout or another workgroup raised the status word).
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int nflags, unsigned need, unsigned* status,
+                                           int* abort_lds) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    int bad = 0;
+    unsigned spins = 0;
+    while (true) {
+      bool ok = true;
+      for (int i = lane; i < nflags; i += 64)
+        ok = ok && (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need);
+      if (__all(ok)) break;
+      if ((++spins & 63u) == 0u) {
+        unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st != 0u || wall_clock64() - t0 > SPIN_LIMIT_TICKS) {
+          if (lane == 0 && st == 0u) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bad = 1;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0) *abort_lds = bad;
+  }
+  __syncthreads();
+  return *abort_lds == 0;
+}
+
+// Every storing wave drains its (write-through) stores, the workgroup meets, ONE lane publishes the flag.
+__device__ __forceinline__ void publish_flag(unsigned* flag, unsigned value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward recurrence
+// dynamic LDS: Wl[4*Hs][LDW] | part[4][MT][NT][64] f32x4 | abort flag
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) lstm_fwd_kernel(const LstmK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Wl = reinterpret_cast<float*>(smem);
+  f32x4* part = reinterpret_cast<f32x4*>(Wl + 4 * p.Hs * p.LDW);
+  int* abort_lds = reinterpret_cast<int*>(part + 4 * MT * NT * 64);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int d = blockIdx.x / p.NC, wg = blockIdx.x % p.NC;
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Bp = p.Bp, LDW = p.LDW;
+  const int j0 = wg * p.Hs;
+  const int R = 4 * p.Hs;
+
+  // stage this workgroup's rows of W_hh: LDS row r = 4*ul + g  <->  torch row g*H + j0 + ul
+  {
+    const float* W = p.w_hh[d];
+    for (int idx = tid; idx < R * LDW; idx += 256) {
+      const int r = idx / LDW, k = idx % LDW;
+      Wl[idx] = (k < H) ? W[(long)((r & 3) * H + j0 + (r >> 2)) * H + k] : 0.f;
+    }
+    if (tid == 0) *abort_lds = 0;
+  }
+
+  const long hx_floats = (long)(H / 4) * Bp * 4;
+  __amdgpu_buffer_rsrc_t hx_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    hx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(p.hx + ((long)par * D + d) * hx_floats, 0, (int)(hx_floats * 4),
+                                                     RSRC_FLAGS);
+  unsigned* flags = p.flags + d * p.NC;
+
+  // cell ownership: threads [0, MT*NT*64): tile (mt, nt), lane (n, q) -> unit 4*mt+q, batch 16*nt+n
+  const bool owner = tid < MT * NT * 64;
+  const int omt = owner ? (tid >> 6) / NT : 0, ont = owner ? (tid >> 6) % NT : 0;
+  const int ob = 16 * ont + n, oj = j0 + 4 * omt + q;
+  const int olen = (owner && ob < B) ? p.lens[ob] : 0;
+  float c_state = 0.f;
+
+  const int KG = (H + 15) / 16, KGW = (KG + 3) / 4;
+  const int kg_begin = wave * KGW, kg_end = min(KG, kg_begin + KGW);
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = (d == 0) ? s : T - 1 - s;
+    // (1) this cell's gate pre-activations (independent of the recurrence: issue first)
+    f32x4 xp = {0.f, 0.f, 0.f, 0.f};
+    const long grow = ((long)t * B + ob) * D + d;
+    if (owner && ob < B) xp = *reinterpret_cast<const f32x4*>(p.gates + grow * 4 * H + 4 * oj);
+
+    // (2) h_{t-1} . W_hh^T for this slice, split-K over the four waves
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return;
+      const __amdgpu_buffer_rsrc_t hr = hx_rsrc[(s - 1) & 1];
+      for (int kg0 = kg_begin; kg0 < kg_end; kg0 += 8) {
+        i32x4 hf[8][NT];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          if (kg0 + g < kg_end) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              hf[g][j] = __builtin_amdgcn_raw_buffer_load_b128(hr, ((4 * (kg0 + g) + q) * Bp + 16 * j + n) * 16, 0, AUX_SC1);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          if (kg0 + g < kg_end) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              const f32x4 a = *reinterpret_cast<const f32x4*>(&Wl[(16 * i + n) * LDW + 16 * (kg0 + g) + 4 * q]);
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                const f32x4 h = __builtin_bit_cast(f32x4, hf[g][j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], h[e], acc[i][j], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+    // (3) partial tiles -> LDS, reduce, gate math
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) part[((wave * MT + i) * NT + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+    if (owner) {
+      f32x4 g4 = xp;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) g4 += part[((w * MT + omt) * NT + ont) * 64 + lane];
+      const bool active = t < olen;
+      float hval = 0.f;
+      f32x4 gact = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+        c_state = fg * c_state + ig * gg;
+        hval = og * tanhf(c_state);
+        gact = (f32x4){ig, fg, gg, og};
+      } else {
+        c_state = 0.f;
+      }
+      // gather the 4 units of this tile row-group into lanes q == 0 (same wave: lanes n, n+16, n+32, n+48)
+      f32x4 h4, c4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h4[e] = __shfl(hval, n + 16 * e);
+        c4[e] = __shfl(c_state, n + 16 * e);
+      }
+      if (q == 0) {  // exchange slice first: it is what the other workgroups wait for
+        const int chunk = (j0 >> 2) + omt;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h4), hx_rsrc[s & 1], (chunk * Bp + ob) * 16, 0, AUX_SC1);
+      }
+      if (ob < B) {
+        *reinterpret_cast<f32x4*>(p.gates + grow * 4 * H + 4 * oj) = gact;
+        if (q == 0) {
+          const int chunk = (j0 >> 2) + omt;
+          *reinterpret_cast<f32x4*>(p.cst + ((((long)d * T + t) * (H / 4) + chunk) * B + ob) * 4) = c4;
+          const long yo = grow * H + j0 + 4 * omt;
+          *reinterpret_cast<f32x4*>(p.y + yo) = h4;
+          if (p.ydrop) {
+            f32x4 hd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              hd[e] = (hash_u32(p.seed, (unsigned long long)(yo + e)) >= p.drop_thresh) ? h4[e] * p.keep_scale : 0.f;
+            *reinterpret_cast<f32x4*>(p.ydrop + yo) = hd;
+          }
+        }
+      }
+    }
+    // (4) publish step s
+    publish_flag(flags + wg, (unsigned)(s + 1));
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward recurrence
+//   dh_t = dy_t + dG_{t'} . W_hh   (t' = the step processed just before), contraction over all 4H gate rows
+//   v_mfma_f32_4x4x1_16B_f32: block = one hidden unit j' of a 16-unit group, A rows = this slice's 4 units,
+//   B cols = 4 batch rows, 4 instructions (one per gate) per (16-unit group, batch quad).
+// dynamic LDS: WT[UG][MT][64] f32x4 | part[16][MT*BG*16] floats | abort flag
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_ror_add(float x) {
+  // sum over the 4 lanes of each 16-lane row that share lane%4 (row_ror:4, row_ror:8)
+  int xi = __builtin_bit_cast(int, x);
+  float y = x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x124, 0xf, 0xf, false));
+  int yi = __builtin_bit_cast(int, y);
+  return y + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(yi, yi, 0x128, 0xf, 0xf, false));
+}
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) lstm_bwd_kernel(const LstmK p) {
+  constexpr int BG = 4 * NT;  // batch quads
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Bp = p.Bp;
+  const int UG = (H + 15) / 16, UGW = (UG + 3) / 4;
+  f32x4* WT = reinterpret_cast<f32x4*>(smem);
+  float* part = reinterpret_cast<float*>(WT + UG * MT * 64);
+  int* abort_lds = reinterpret_cast<int*>(part + 16 * MT * BG * 16);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = lane >> 2, l4 = lane & 3, row = lane >> 4;
+  const int d = blockIdx.x / p.NC, wg = blockIdx.x % p.NC;
+  const int j0 = wg * p.Hs;
+
+  // stage W_hh columns of this slice: WT[ug][m][lane = 4*blk + i][e] = W_hh[e*H + 16*ug + blk][j0 + 4*m + i]
+  {
+    const float* W = p.w_hh[d];
+    for (int idx = tid; idx < UG * MT * 64; idx += 256) {
+      const int ln = idx & 63, m = (idx >> 6) % MT, ug = (idx >> 6) / MT;
+      const int jp = 16 * ug + (ln >> 2), jj = j0 + 4 * m + (ln & 3);
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (jp < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = W[(long)(e * H + jp) * H + jj];
+      }
+      WT[idx] = w;
+    }
+    if (tid == 0) *abort_lds = 0;
+  }
+
+  const long gx_floats = (long)H * Bp * 4;
+  __amdgpu_buffer_rsrc_t gx_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    gx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(p.hx + ((long)par * D + d) * gx_floats, 0, (int)(gx_floats * 4),
+                                                     RSRC_FLAGS);
+  unsigned* flags = p.flags + d * p.NC;
+
+  // cell ownership: tid = ((m*BG + bg)*4 + i)*4 + jb  -> unit j0 + 4m + i, batch 4*bg + jb
+  const bool owner = tid < MT * BG * 16;
+  const int ojb = tid & 3, oi = (tid >> 2) & 3, obg = (tid >> 4) % BG, om = (tid >> 4) / BG;
+  const int ob = 4 * obg + ojb, oj = j0 + 4 * om + oi;
+  const int olen = (owner && ob < B) ? p.lens[ob] : 0;
+  const int ochunk = oj >> 2;
+  float dc_carry = 0.f;
+
+  const int ug_begin = wave * UGW, ug_end = min(UG, ug_begin + UGW);
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = (d == 0) ? T - 1 - s : s;
+    const int tprev = (d == 0) ? t - 1 : t + 1;  // where c_{prev} of the forward recurrence lives
+    // (1) prefetch this cell's stash (independent of the recurrence)
+    f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+    float c_t = 0.f, c_p = 0.f, dyv = 0.f;
+    const long grow = ((long)t * B + ob) * D + d;
+    const bool active = owner && ob < B && t < olen;
+    if (active) {
+      gt = *reinterpret_cast<const f32x4*>(p.gates + grow * 4 * H + 4 * oj);
+      c_t = p.cst[((((long)d * T + t) * (H / 4) + ochunk) * B + ob) * 4 + (oj & 3)];
+      if (tprev >= 0 && tprev < T) c_p = p.cst[((((long)d * T + tprev) * (H / 4) + ochunk) * B + ob) * 4 + (oj & 3)];
+      const long yo = grow * H + oj;
+      dyv = p.dy[yo];
+      if (p.ydrop) dyv = (hash_u32(p.seed, (unsigned long long)yo) >= p.drop_thresh) ? dyv * p.keep_scale : 0.f;
+    }
+
+    // (2) dG_{prev step} . W_hh[:, slice], split over unit groups (K) across the four waves
+    f32x4 acc[MT][BG];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < BG; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return;
+      const __amdgpu_buffer_rsrc_t gr = gx_rsrc[(s - 1) & 1];
+      for (int ug = ug_begin; ug < ug_end; ++ug) {
+        i32x4 gf[BG];
+#pragma unroll
+        for (int g = 0; g < BG; ++g)
+          gf[g] = __builtin_amdgcn_raw_buffer_load_b128(gr, ((16 * ug + blk) * Bp + 4 * g + l4) * 16, 0, AUX_SC1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const f32x4 w = WT[(ug * MT + m) * 64 + lane];
+#pragma unroll
+          for (int g = 0; g < BG; ++g) {
+            const f32x4 x = __builtin_bit_cast(f32x4, gf[g]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[m][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[e], x[e], acc[m][g], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // (3) sum the 16 k-blocks: 4 lanes per row by DPP, then 4 rows x 4 waves through LDS
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < BG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = dpp_ror_add(acc[m][g][i]);
+          if ((lane & 15) < 4) part[(wave * 4 + row) * (MT * BG * 16) + ((m * BG + g) * 4 + i) * 4 + l4] = v;
+        }
+    __syncthreads();
+    if (owner) {
+      float dh = dyv;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dh += part[k * (MT * BG * 16) + tid];
+      f32x4 dg4 = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
+        const float tc = tanhf(c_t);
+        const float dc = dh * og * (1.f - tc * tc) + dc_carry;
+        dg4[0] = dc * gg * ig * (1.f - ig);
+        dg4[1] = dc * c_p * fg * (1.f - fg);
+        dg4[2] = dc * ig * (1.f - gg * gg);
+        dg4[3] = dh * tc * og * (1.f - og);
+        dc_carry = dc * fg;
+      } else {
+        dc_carry = 0.f;
+      }
+      // exchange first (what the other workgroups wait for), then the stash for the weight-gradient GEMMs
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dg4), gx_rsrc[s & 1], (oj * Bp + ob) * 16, 0, AUX_SC1);
+      if (ob < B) *reinterpret_cast<f32x4*>(p.gates + grow * 4 * H + 4 * oj) = dg4;
+    }
+    // (4) publish step s
+    publish_flag(flags + wg, (unsigned)(s + 1));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+// out[(d*4H + 4j+g)*I + k] = w[d][(g*H + j)*I + k]
+__global__ void permute_w_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int H, int I,
+                                 float* __restrict__ out) {
+  const long per = (long)4 * H * I;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int d = blockIdx.y;
+  if (idx >= per) return;
+  const int k = (int)(idx % I), r = (int)(idx / I);
+  const float* w = d ? w1 : w0;
+  out[d * per + idx] = w[(long)((r & 3) * H + (r >> 2)) * I + k];
+}
+// inverse for gradients: dw[d][(g*H + j)*I + k] = in[(d*4H + 4j+g)*I + k]
+__global__ void unpermute_w_kernel(const float* __restrict__ in, int H, int I, long in_dir_stride, float* __restrict__ o0,
+                                   float* __restrict__ o1) {
+  const long per = (long)4 * H * I;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int d = blockIdx.y;
+  if (idx >= per) return;
+  const int k = (int)(idx % I), r = (int)(idx / I);
+  float* o = d ? o1 : o0;
+  o[(long)((r & 3) * H + (r >> 2)) * I + k] = in[d * in_dir_stride + idx];
+}
+__global__ void permute_bias_kernel(const float* __restrict__ bi0, const float* __restrict__ bh0,
+                                    const float* __restrict__ bi1, const float* __restrict__ bh1, int H,
+                                    float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int d = blockIdx.y;
+  if (idx >= 4 * H) return;
+  const int src = (idx & 3) * H + (idx >> 2);
+  out[d * 4 * H + idx] = d ? bi1[src] + bh1[src] : bi0[src] + bh0[src];
+}
+
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X, long M, long N, long ld,
+                                                     float* __restrict__ out) {
+  // block = 64 columns x 4 row-lanes; grid.x over column tiles; fixed-order reduction (deterministic)
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const long n = (long)blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (n < N)
+    for (long m = r; m < M; m += 4) s += X[m * ld + n];
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0 && n < N) out[n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+__global__ void embedding_fwd_kernel(const float* __restrict__ W, const long* __restrict__ idx, long M, int H, int V,
+                                     float* __restrict__ out) {
+  const long total = M * H;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / H;
+    const int h = (int)(i % H);
+    const long v = idx[m];
+    out[i] = (v >= 0 && v < V) ? W[v * H + h] : 0.f;
+  }
+}
+
+__global__ void embedding_bwd_kernel(const float* __restrict__ dE, const long* __restrict__ idx, long M, int H, int V,
+                                     long pad, float* __restrict__ dW) {
+  // one workgroup per vocabulary row: fixed-order sum over the tokens that hit it (deterministic, no atomics)
+  const int v = blockIdx.x;
+  if (v == pad) return;
+  for (int h = threadIdx.x; h < H; h += blockDim.x) {
+    float s = 0.f;
+    for (long m = 0; m < M; ++m)
+      if (idx[m] == v) s += dE[m * H + h];
+    dW[(long)v * H + h] = s;
+  }
+}
+
+struct LstmWs {
+  unsigned* flags;  // [16 words: status at word 0] [D*NC step flags], zeroed per launch
+  size_t sync_bytes;
+  float* hx;
+  size_t hx_bytes;
+  float* wp;   // (D*4H, I) permuted input weights; reused as dW_ih' in backward
+  float* bp;   // (D*4H)
+  float* dwhh; // (D*4H, H) scratch for dW_hh'
+  size_t total;
+};
+
+struct Plan {
+  int Hs, NC, MT, NT, Bp, LDW, wgs_per_cu;
+  size_t lds_fwd, lds_bwd;
+};
+
+bool make_plan(int B, int H, int D, int cus, Plan* pl) {
+  if (H < 4 || H % 4 != 0 || B < 1 || B > 64 || D < 1 || D > 2) return false;
+  const int NT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+  pl->NT = NT;
+  pl->Bp = 16 * NT;
+  const int KG = (H + 15) / 16;
+  pl->LDW = 16 * KG + 4;
+  for (int per_cu = 1; per_cu <= 2; ++per_cu) {
+    for (int Hs = 4; Hs <= 16; Hs *= 2) {
+      if (H % Hs != 0) continue;
+      const int MT = Hs / 4, NC = H / Hs;
+      const size_t lds_fwd = (size_t)4 * Hs * pl->LDW * 4 + (size_t)4 * MT * NT * 64 * 16 + 16;
+      const size_t lds_bwd = (size_t)KG * MT * 64 * 16 + (size_t)16 * MT * 4 * NT * 16 * 4 + 16;
+      const size_t lds = lds_fwd > lds_bwd ? lds_fwd : lds_bwd;
+      if (lds * per_cu > 160 * 1024) continue;
+      if ((long)D * NC > (long)cus * per_cu) continue;
+      pl->Hs = Hs; pl->NC = NC; pl->MT = MT; pl->wgs_per_cu = per_cu;
+      pl->lds_fwd = lds_fwd; pl->lds_bwd = lds_bwd;
+      return true;
+    }
+  }
+  return false;
+}
+
+LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
+  LstmWs w;
+  char* p = reinterpret_cast<char*>(ws);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off += align_up(bytes, 256); return q; };
+  w.sync_bytes = align_up((size_t)(D * pl.NC + 16) * 4, 16);
+  w.flags = reinterpret_cast<unsigned*>(take(w.sync_bytes));
+  w.hx_bytes = (size_t)2 * D * H * pl.Bp * 4 * 4;  // sized for the backward exchange (B x 4H), fwd uses a quarter
+  w.hx = reinterpret_cast<float*>(take(w.hx_bytes));
+  w.wp = reinterpret_cast<float*>(take((size_t)D * 4 * H * I * 4));
+  w.bp = reinterpret_cast<float*>(take((size_t)D * 4 * H * 4));
+  w.dwhh = reinterpret_cast<float*>(take((size_t)D * 4 * H * H * 4));
+  w.total = off;
+  (void)T; (void)B;
+  return w;
+}
+
+int device_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return cus;
+}
+
+template <typename K>
+int launch_persistent(K kernel, const LstmK& k, const Plan& pl, size_t lds, hipStream_t s, const char* what) {
+  if (lds > 64 * 1024)
+    RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  RNNT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
+  const int cus = device_cus();
+  if (per_cu < 1 || (long)k.D * k.NC > (long)cus * (per_cu < pl.wgs_per_cu ? per_cu : pl.wgs_per_cu)) {
+    set_error("%s: %d workgroups cannot be co-resident (%d CUs x %d per CU)", what, k.D * k.NC, cus, per_cu);
+    return RNNT_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(kernel, dim3(k.D * k.NC), dim3(256), lds, s, k);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+int check_desc(const rnnt_lstm_desc* d, Plan* pl, LstmWs* w) {
+  RNNT_CHECK_ARG(d != nullptr, "lstm: null descriptor");
+  RNNT_CHECK_ARG(d->T >= 1 && d->I >= 1, "lstm: T and I must be positive (T=%d I=%d)", d->T, d->I);
+  const int cus = device_cus();
+  RNNT_CHECK_ARG(cus > 0, "lstm: no HIP device");
+  if (!make_plan(d->B, d->H, d->D, cus, pl)) {
+    set_error("lstm: unsupported configuration B=%d H=%d D=%d (need H%%4==0, 1<=B<=64, D in {1,2}, slice must fit %d CUs)",
+              d->B, d->H, d->D, cus);
+    return RNNT_ERR_UNSUPPORTED;
+  }
+  RNNT_CHECK_ARG(d->lens && d->x && d->y && d->gates && d->cst, "lstm: null tensor");
+  for (int k = 0; k < d->D; ++k)
+    RNNT_CHECK_ARG(d->w_ih[k] && d->w_hh[k] && d->b_ih[k] && d->b_hh[k], "lstm: null weight (direction %d)", k);
+  RNNT_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "lstm: dropout_p must be in [0,1)");
+  RNNT_CHECK_ARG(d->dropout_p == 0.f || d->y_drop, "lstm: dropout_p > 0 needs y_drop");
+  *w = carve_lstm(d->workspace, d->T, d->B, d->I, d->H, d->D, *pl);
+  RNNT_CHECK_ARG(d->workspace && d->workspace_bytes >= w->total, "lstm: workspace too small (%zu < %zu)",
+                 d->workspace_bytes, w->total);
+  RNNT_CHECK_ARG((reinterpret_cast<uintptr_t>(d->gates) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(d->cst) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->workspace) & 255) == 0,
+                 "lstm: gates/y/cst must be 16-byte aligned, workspace 256-byte aligned");
+  return RNNT_OK;
+}
+
+void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, LstmK* k) {
+  k->T = d->T; k->B = d->B; k->H = d->H; k->D = d->D;
+  k->Hs = pl.Hs; k->NC = pl.NC; k->Bp = pl.Bp; k->LDW = pl.LDW;
+  k->lens = d->lens; k->gates = d->gates; k->cst = d->cst; k->y = d->y;
+  k->ydrop = d->dropout_p > 0.f ? d->y_drop : nullptr;
+  k->keep_scale = d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f;
+  k->drop_thresh = (unsigned)((double)d->dropout_p * 4294967296.0);
+  k->seed = d->dropout_seed;
+  k->w_hh[0] = d->w_hh[0]; k->w_hh[1] = d->D > 1 ? d->w_hh[1] : d->w_hh[0];
+  k->hx = w.hx; k->status = w.flags; k->flags = w.flags + 16;
+  k->dy = nullptr;
+}
+
+}  // namespace
+}  // namespace rnnt
+
+using namespace rnnt;
+
+extern "C" size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D) {
+  Plan pl;
+  int cus = device_cus();
+  if (cus <= 0) cus = 256;  // sizing query without a device: assume MI355X
+  if (T < 1 || I < 1 || !make_plan(B, H, D, cus, &pl)) return 0;
+  return carve_lstm(nullptr, T, B, I, H, D, pl).total;
+}
+
+#define DISPATCH_MT_NT(KERNEL, pl, ...)                                                     \
+  do {                                                                                      \
+    const int key_ = (pl).MT * 10 + (pl).NT;                                                \
+    switch (key_) {                                                                         \
+      case 11: rc = launch_persistent(KERNEL<1, 1>, __VA_ARGS__); break;                    \
+      case 12: rc = launch_persistent(KERNEL<1, 2>, __VA_ARGS__); break;                    \
+      case 14: rc = launch_persistent(KERNEL<1, 4>, __VA_ARGS__); break;                    \
+      case 21: rc = launch_persistent(KERNEL<2, 1>, __VA_ARGS__); break;                    \
+      case 22: rc = launch_persistent(KERNEL<2, 2>, __VA_ARGS__); break;                    \
+      case 24: rc = launch_persistent(KERNEL<2, 4>, __VA_ARGS__); break;                    \
+      case 41: rc = launch_persistent(KERNEL<4, 1>, __VA_ARGS__); break;                    \
+      case 42: rc = launch_persistent(KERNEL<4, 2>, __VA_ARGS__); break;                    \
+      case 44: rc = launch_persistent(KERNEL<4, 4>, __VA_ARGS__); break;                    \
+      default: set_error("lstm: no kernel for MT=%d NT=%d", (pl).MT, (pl).NT); rc = RNNT_ERR_UNSUPPORTED; \
+    }                                                                                       \
+  } while (0)
+
+extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
+  Plan pl;
+  LstmWs w;
+  if (int rc = check_desc(d, &pl, &w)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int H = d->H, D = d->D, I = d->I;
+  // 1. gate-adjacent copy of W_ih (both directions stacked) and of b_ih + b_hh
+  {
+    const long per = (long)4 * H * I;
+    hipLaunchKernelGGL(permute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, d->w_ih[0],
+                       D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, w.wp);
+    RNNT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(permute_bias_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, d->b_ih[0], d->b_hh[0],
+                       D > 1 ? d->b_ih[1] : d->b_ih[0], D > 1 ? d->b_hh[1] : d->b_hh[0], H, w.bp);
+    RNNT_CHECK_LAUNCH();
+  }
+  // 2. hoisted input projection for all timesteps: gates[(t,b)][d*4H + 4j+g] = x(t,b,:) . W_ih'[.] + bias'
+  {
+    rnnt_gemm_desc g = {};
+    g.M = (int64_t)d->T * d->B; g.N = (int64_t)D * 4 * H; g.K = I;
+    g.A = d->x; g.a_div = d->B; g.a_so = d->x_st; g.a_si = d->x_sb; g.a_sk = 1; g.a_mc = 0;
+    g.B = w.wp; g.b_sn = I; g.b_sk = 1;
+    g.C = d->gates; g.c_div = 1; g.c_so = g.N; g.c_si = 0;
+    g.bias = w.bp;
+    if (int rc = rnnt_hip_gemm_f32(&g, s)) return rc;
+  }
+  // 3. the recurrence
+  RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, w.sync_bytes, s));
+  RNNT_CHECK_HIP(hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+  LstmK k;
+  fill_kernel_args(d, pl, w, &k);
+  int rc = RNNT_OK;
+  DISPATCH_MT_NT(lstm_fwd_kernel, pl, k, pl, pl.lds_fwd, s, "lstm_fwd");
+  return rc;
+}
+
+extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
+  RNNT_CHECK_ARG(bd != nullptr, "lstm_bwd: null descriptor");
+  const rnnt_lstm_desc* d = &bd->f;
+  Plan pl;
+  LstmWs w;
+  if (int rc = check_desc(d, &pl, &w)) return rc;
+  RNNT_CHECK_ARG(bd->dy, "lstm_bwd: null dy");
+  const int T = d->T, B = d->B, H = d->H, D = d->D, I = d->I;
+  RNNT_CHECK_ARG(d->x_sb == I && d->x_st == (int64_t)B * I, "lstm_bwd: x must be time-major contiguous (T,B,I)");
+  for (int k = 0; k < D; ++k) RNNT_CHECK_ARG(bd->dw_ih[k] && bd->dw_hh[k] && bd->db[k], "lstm_bwd: null gradient output");
+  hipStream_t s = (hipStream_t)stream;
+
+  // 1. reverse-time recurrence: gates (activated) -> dG in place
+  RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, w.sync_bytes, s));
+  RNNT_CHECK_HIP(hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+  LstmK k;
+  fill_kernel_args(d, pl, w, &k);
+  k.dy = bd->dy;
+  int rc = RNNT_OK;
+  DISPATCH_MT_NT(lstm_bwd_kernel, pl, k, pl, pl.lds_bwd, s, "lstm_bwd");
+  if (rc) return rc;
+
+  const int64_t M = (int64_t)T * B, N4 = (int64_t)D * 4 * H;
+  // 2. dX = dG . W_ih'   (needs the permuted weights: rebuild them, the forward copy may have been overwritten)
+  if (bd->dx) {
+    const long per = (long)4 * H * I;
+    hipLaunchKernelGGL(permute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, d->w_ih[0],
+                       D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, w.wp);
+    RNNT_CHECK_LAUNCH();
+    rnnt_gemm_desc g = {};
+    g.M = M; g.N = I; g.K = N4;
+    g.A = d->gates; g.a_div = 1; g.a_so = N4; g.a_si = 0; g.a_sk = 1; g.a_mc = 0;
+    g.B = w.wp; g.b_sn = 1; g.b_sk = I;
+    g.C = bd->dx; g.c_div = 1; g.c_so = I; g.c_si = 0;
+    if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
+  }
+  // 3. dW_ih' = dG^T . X  (both directions at once), un-permute rows into torch layout
+  {
+    rnnt_gemm_desc g = {};
+    g.M = N4; g.N = I; g.K = M;
+    g.A = d->gates; g.a_mc = 1; g.a_sk = N4; g.a_div = 1;
+    g.B = d->x; g.b_sn = 1; g.b_sk = I;
+    g.C = w.wp; g.c_div = 1; g.c_so = I; g.c_si = 0;
+    if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
+    const long per = (long)4 * H * I;
+    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per,
+                       bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0]);
+    RNNT_CHECK_LAUNCH();
+  }
+  // 4. dW_hh'[d] = sum_t dG[t]^T . h_prev(t): time-shifted views of dG and y (padded frames are zero in both)
+  for (int dir = 0; dir < D; ++dir) {
+    rnnt_gemm_desc g = {};
+    g.M = 4 * H; g.N = H; g.K = (int64_t)(T - 1) * B;
+    const int64_t shift_g = dir == 0 ? (int64_t)B * N4 : 0;           // dG rows t = 1..T-1 | 0..T-2
+    const int64_t shift_y = dir == 0 ? 0 : (int64_t)B * D * H;        // y  rows t = 0..T-2 | 1..T-1
+    g.A = d->gates + shift_g + (int64_t)dir * 4 * H; g.a_mc = 1; g.a_sk = N4; g.a_div = 1;
+    g.B = d->y + shift_y + (int64_t)dir * H; g.b_sn = 1; g.b_sk = (int64_t)D * H;
+    g.C = w.dwhh + (int64_t)dir * 4 * H * H; g.c_div = 1; g.c_so = H; g.c_si = 0;
+    if (g.K > 0) {
+      if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
+    } else {
+      RNNT_CHECK_HIP(hipMemsetAsync(g.C, 0, (size_t)4 * H * H * 4, s));
+    }
+  }
+  {
+    const long per = (long)4 * H * H;
+    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.dwhh, H, H, per,
+                       bd->dw_hh[0], D > 1 ? bd->dw_hh[1] : bd->dw_hh[0]);
+    RNNT_CHECK_LAUNCH();
+  }
+  // 5. bias gradient = column sums of dG, un-permuted
+  {
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N4, 64)), dim3(256), 0, s, d->gates, (long)M, (long)N4, (long)N4, w.bp);
+    RNNT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, w.bp, H, 1, (long)4 * H,
+                       bd->db[0], D > 1 ? bd->db[1] : bd->db[0]);
+    RNNT_CHECK_LAUNCH();
+  }
+  return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_lstm_check(const void* workspace, void* stream) {
+  // word 0 of the workspace is the persistent kernels' status word (0 = ok, 1 = an inter-CU wait gave up)
+  RNNT_CHECK_ARG(workspace != nullptr, "lstm_check: null workspace");
+  unsigned st = 0;
+  RNNT_CHECK_HIP(hipMemcpyAsync(&st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RNNT_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (st != 0) {
+    set_error("persistent LSTM kernel abandoned an inter-workgroup wait (status %u)", st);
+    return RNNT_ERR_TIMEOUT;
+  }
+  return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream) {
+  RNNT_CHECK_ARG(X && out && M >= 0 && N >= 1 && ld >= N, "colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, X, (long)M, (long)N, (long)ld, out);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_embedding_fwd(const float* W, const int64_t* idx, int64_t M, int32_t H, int32_t V, float* out,
+                                      void* stream) {
+  RNNT_CHECK_ARG(W && idx && out && M >= 0 && H >= 1 && V >= 1, "embedding_fwd: bad arguments");
+  if (M == 0) return RNNT_OK;
+  const long blocks = ceil_div(M * H, 256);
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, W,
+                     (const long*)idx, (long)M, H, V, out);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_embedding_bwd(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V,
+                                      int64_t padding_idx, float* dW, void* stream) {
+  RNNT_CHECK_ARG(dE && idx && dW && M >= 0 && H >= 1 && V >= 1, "embedding_bwd: bad arguments");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, dE, (const long*)idx, (long)M, H, V,
+                     (long)padding_idx, dW);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}

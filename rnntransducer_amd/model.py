@@ -1,0 +1,67 @@
+"""RNNTransducer — the LightningModule surface of the reference's model.py on the MI355X HIP path.
+
+Same constructor `(prednet_params, transnet_params, jointnet_params, args)`, same `forward`, `training_step`
+(7-tuple batch of dataloader.py:49) and `configure_optimizers` (AdamW + OneCycleLR per step, model.py:110-126),
+same attribute `jointnet` and therefore the same state_dict keys.  Inherits
+pytorch_lightning.LightningModule when that package is importable, torch.nn.Module otherwise.
+
+Differences, all inside the hot path:
+  * `training_step` runs the FUSED joint + RNN-T loss (`JointNet.loss`): the (B,T,U+1,V) logits tensor the
+    reference builds at model.py:56 is never materialised.  `forward()` still returns it on request.
+  * blank/pad id comes from `args.blank_token_id` / `prednet_params["pad_token_id"]` (default 0, as in the shipped
+    config.json:37,40) instead of loading a tokenizer (model.py:24-26): tokenizer, WER/CER and decoding are
+    validation-side and out of scope.
+"""
+from argparse import Namespace
+
+import torch
+
+from .loss import RNNTLoss
+from .networks import JointNet
+
+try:  # pragma: no cover - not installed in the build image
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    pl = None
+    _Base = torch.nn.Module
+
+
+class RNNTransducer(_Base):
+    def __init__(self, prednet_params: dict, transnet_params: dict, jointnet_params: dict, args: Namespace):
+        super().__init__()
+        if pl is not None:
+            self.save_hyperparameters(prednet_params, transnet_params, jointnet_params, args)
+        self.args = args
+        prednet_params = dict(prednet_params)
+        blank = getattr(args, "blank_token_id", None)
+        if blank is None:
+            blank = prednet_params.get("pad_token_id", 0)
+        self.blank_token_id = int(blank)
+        prednet_params["pad_token_id"] = self.blank_token_id  # model.py:26
+        self.jointnet = JointNet(dict(transnet_params), prednet_params, **jointnet_params)
+        # model.py:28-39 picks torchaudio (precision 16) or warp-transducer; both are this one HIP module here
+        self.rnnt_loss = RNNTLoss(blank=self.blank_token_id, reduction="mean")
+
+    def forward(self, input_audios, audio_lengths, input_texts, text_lengths):
+        return self.jointnet(input_audios, audio_lengths, input_texts, text_lengths)
+
+    def training_step(self, batch, batch_idx):
+        assert not getattr(self.args, "move_metrics_to_cpu", False), "DDP only (model.py:53)"
+        input_audios, audio_lengths, tensor_audio_lengths, input_texts, text_lengths, targets, target_lengths = batch
+        nll = self.jointnet.loss(input_audios, tensor_audio_lengths, input_texts, targets, target_lengths,
+                                 self.blank_token_id)
+        loss = nll.mean()  # reduction="mean" (model.py:39)
+        if pl is not None and getattr(self, "_trainer", None) is not None:
+            self.log("train_loss", loss, sync_dist=True)
+        return {"loss": loss}
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.AdamW([{"params": [p for p in self.parameters()], "name": "OneCycleLR"}],
+                                      lr=self.args.learning_rate, weight_decay=self.args.weight_decay)
+        trainer = getattr(self, "_trainer", None)
+        total = trainer.estimated_stepping_batches if trainer is not None else int(getattr(self.args, "total_steps"))
+        scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=self.args.learning_rate, total_steps=total,
+                                                        pct_start=self.args.warmup_ratio,
+                                                        final_div_factor=self.args.final_div_factor)
+        return {"optimizer": optimizer, "lr_scheduler": {"interval": "step", "scheduler": scheduler, "name": "AdamW"}}

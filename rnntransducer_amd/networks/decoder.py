@@ -1,0 +1,49 @@
+"""TextPredNet — prediction network (training branch) on the MI355X HIP path.
+
+Mirrors networks/decoder.py:57-80 (ctor) and :82-126 (forward, packed branch :102-120,124) of the reference:
+Embedding(V, H, padding_idx=blank) -> LSTM -> Linear(H -> O); returns (outputs, hidden_states).
+The single-step branch (`prev_hidden_state`, decoder.py:121-123) belongs to greedy/beam decoding, which is
+out of scope for the training hot path: it raises NotImplementedError here.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..ops import EmbeddingFn
+from .encoder import HipLinear, lengths_to_device
+from .rnn import HipLSTM
+
+
+class HipEmbedding(nn.Embedding):
+    """nn.Embedding parameters (row padding_idx zero-initialised, no gradient), gather/scatter in HIP."""
+
+    def forward(self, idx: torch.Tensor) -> torch.Tensor:
+        return EmbeddingFn.apply(self.weight, idx, self.padding_idx)
+
+
+class TextPredNet(nn.Module):
+    supported_rnns = ("lstm",)
+
+    def __init__(self, embedding_size: int, pad_token_id: int, hidden_size: int, output_size: int, num_layers: int,
+                 rnn_type: str = "lstm", dropout: float = 0.2):
+        super().__init__()
+        if rnn_type.lower() not in self.supported_rnns:
+            raise NotImplementedError(f"rnn_type={rnn_type!r}: only 'lstm' has a HIP kernel in this version")
+        self.hidden_size = hidden_size
+        self.embedding = HipEmbedding(embedding_size, hidden_size, padding_idx=pad_token_id)
+        self.rnn = HipLSTM(hidden_size, hidden_size, num_layers, dropout=(dropout if num_layers > 1 else 0.0),
+                           bidirectional=False)
+        self.out_proj = HipLinear(hidden_size, output_size)
+
+    def forward_time_major(self, inputs: torch.Tensor, lens_dev: torch.Tensor) -> torch.Tensor:
+        """(B,U1) int64 tokens + int32 device lengths -> (U1,B,O) time-major."""
+        emb = self.embedding(inputs.transpose(0, 1).contiguous())  # (U1,B,H)
+        return self.out_proj(self.rnn(emb, lens_dev))
+
+    def forward(self, inputs: torch.Tensor, input_lengths=None,
+                prev_hidden_state: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, None]:
+        if prev_hidden_state is not None or input_lengths is None:
+            raise NotImplementedError("single-step decoding branch (decoder.py:121-123) is outside the training hot path")
+        lens = lengths_to_device(input_lengths, inputs.device)
+        return self.forward_time_major(inputs, lens).transpose(0, 1).contiguous(), None

@@ -1,0 +1,53 @@
+"""HipLSTM: parameter container + forward for the persistent HIP LSTM (no torch.nn.LSTM / MIOpen call).
+
+Parameter names, shapes, gate order (i,f,g,o) and initialisation order are those of torch.nn.LSTM, which the
+reference instantiates at networks/encoder.py:67-75 and networks/decoder.py:71-79, so reference checkpoints
+(`...rnn.weight_ih_l0`, `...rnn.weight_hh_l0_reverse`, ...) load unchanged.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..ops import LstmStackFn
+
+
+class HipLSTM(nn.Module):
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1, dropout: float = 0.0,
+                 bidirectional: bool = False):
+        super().__init__()
+        if hidden_size % 4 != 0:
+            raise ValueError("HipLSTM needs hidden_size % 4 == 0 (each workgroup owns 4-unit slices)")
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.dropout, self.bidirectional = float(dropout), bool(bidirectional)
+        D = 2 if bidirectional else 1
+        for layer in range(num_layers):
+            in_l = input_size if layer == 0 else hidden_size * D
+            for suffix in ("", "_reverse")[:D]:
+                self.register_parameter(f"weight_ih_l{layer}{suffix}", nn.Parameter(torch.empty(4 * hidden_size, in_l)))
+                self.register_parameter(f"weight_hh_l{layer}{suffix}", nn.Parameter(torch.empty(4 * hidden_size, hidden_size)))
+                self.register_parameter(f"bias_ih_l{layer}{suffix}", nn.Parameter(torch.empty(4 * hidden_size)))
+                self.register_parameter(f"bias_hh_l{layer}{suffix}", nn.Parameter(torch.empty(4 * hidden_size)))
+        self.reset_parameters()
+        self._step = 0
+
+    def reset_parameters(self) -> None:
+        stdv = 1.0 / math.sqrt(self.hidden_size)
+        for p in self.parameters():  # registration order == torch.nn.LSTM's, so the same seed gives the same weights
+            nn.init.uniform_(p, -stdv, stdv)
+
+    def flat_weights(self):
+        out = []
+        for layer in range(self.num_layers):
+            for suffix in ("", "_reverse")[:2 if self.bidirectional else 1]:
+                for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    out.append(getattr(self, f"{name}_l{layer}{suffix}"))
+        return out
+
+    def forward(self, x_tm: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+        """x_tm (T,B,I) time-major fp32, lens (B) int32 on the same device -> (T,B,D*H), zeros for t >= lens[b]."""
+        p = self.dropout if (self.training and self.num_layers > 1) else 0.0
+        self._step += 1
+        seed = (torch.initial_seed() * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFFFFFF
+        return LstmStackFn.apply(x_tm, lens, self.hidden_size, self.num_layers, self.bidirectional, p, seed,
+                                 *self.flat_weights())

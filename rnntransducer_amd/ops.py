@@ -1,0 +1,373 @@
+"""torch.autograd wrappers over the C ABI (include/rnnt_hip.h).  PyTorch here is plumbing only: it owns
+device memory and the stream and records the graph; every FLOP below runs in librnnt_hip.so.
+
+All internal activations are TIME-MAJOR (T,B,F): one LSTM step touches one contiguous (B,F) slab.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GEMM_GELU_A, GEMM_GELU_B, GEMM_MUL_DGELU, GemmDesc, LstmBwdDesc, LstmDesc, RnntHipError, check
+
+BIG = 1 << 40  # "no second level" divisor for the GEMM row maps
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RnntHipError("rnntransducer_amd runs on the MI355X only: got a CPU tensor. There is no CPU or "
+                               "eager fallback; move the module and the batch to cuda:<n>.")
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _addr(t: Optional[torch.Tensor], elem_off: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() + elem_off * t.element_size()
+
+
+# --------------------------------------------------------------------------------------------------
+# raw GEMM
+# --------------------------------------------------------------------------------------------------
+def gemm(M: int, N: int, K: int, A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, *, a_off=0, a_div=BIG, a_so=0,
+         a_si=None, a_sk=1, a_mc=False, a_rowidx=None, b_off=0, b_sn=None, b_sk=1, c_off=0, c_div=BIG, c_so=0, c_si=None,
+         bias=None, aux=None, flags=0) -> None:
+    """C(m,n) = sum_k A(m,k) B(k,n) (+bias) — see include/rnnt_hip.h for the operand maps."""
+    _need_gpu(A, B, Cout)
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A = _addr(A, a_off)
+    d.a_div, d.a_so, d.a_si, d.a_sk = a_div, a_so, (K if a_si is None else a_si), a_sk
+    d.a_mc = 1 if a_mc else 0
+    d.a_rowidx = _addr(a_rowidx)
+    d.B = _addr(B, b_off)
+    d.b_sn, d.b_sk = (K if b_sn is None else b_sn), b_sk
+    d.C = _addr(Cout, c_off)
+    d.c_div, d.c_so, d.c_si = c_div, c_so, (N if c_si is None else c_si)
+    d.bias = _addr(bias)
+    d.aux = _addr(aux)
+    d.flags = flags
+    check(_lib.lib().rnnt_hip_gemm_f32(C.byref(d), _stream()), "rnnt_hip_gemm_f32")
+
+
+def colsum(X: torch.Tensor, M: int, N: int, ld: Optional[int] = None) -> torch.Tensor:
+    out = torch.empty(N, device=X.device, dtype=torch.float32)
+    check(_lib.lib().rnnt_hip_colsum_f32(_addr(X), M, N, N if ld is None else ld, _addr(out), _stream()), "colsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# Linear: y = x W^T + b on rows of a 2-D view (replaces nn.Linear: encoder.py:76,103; decoder.py:80,124)
+# --------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        _need_gpu(x, W, bias)
+        x = _f32c(x, "x")
+        W = _f32c(W, "weight")
+        lead, K = x.shape[:-1], x.shape[-1]
+        N = W.shape[0]
+        M = x.numel() // K
+        y = torch.empty(*lead, N, device=x.device, dtype=torch.float32)
+        gemm(M, N, K, x, W, y, bias=bias)
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        N, K = W.shape
+        M = x.numel() // K
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(M, K, N, dy, W, dx, b_sn=1, b_sk=K)          # dx = dy . W
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            gemm(N, K, M, dy, x, dW, a_mc=True, a_sk=N, b_sn=1, b_sk=K)  # dW = dy^T . x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, M, N)
+        return dx, dW, db
+
+
+# --------------------------------------------------------------------------------------------------
+# Embedding (networks/decoder.py:69,102)
+# --------------------------------------------------------------------------------------------------
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, idx, padding_idx):
+        _need_gpu(W, idx)
+        W = _f32c(W, "embedding.weight")
+        if idx.dtype != torch.int64:
+            raise ValueError(f"token ids must be int64 (dataloader.py:28-36), got {idx.dtype}")
+        idx = idx.contiguous()
+        V, H = W.shape
+        out = torch.empty(*idx.shape, H, device=W.device, dtype=torch.float32)
+        check(_lib.lib().rnnt_hip_embedding_fwd(_addr(W), _addr(idx), idx.numel(), H, V, _addr(out), _stream()), "embedding_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (V, H)
+        ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dE):
+        (idx,) = ctx.saved_tensors
+        V, H = ctx.shape
+        dE = _f32c(dE, "dE")
+        dW = torch.zeros(V, H, device=dE.device, dtype=torch.float32)
+        check(_lib.lib().rnnt_hip_embedding_bwd(_addr(dE), _addr(idx), idx.numel(), H, V, ctx.padding_idx, _addr(dW),
+                                                _stream()), "embedding_bwd")
+        return dW, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# LSTM stack (replaces nn.LSTM over a PackedSequence: encoder.py:67-75,93-102; decoder.py:71-79,105-120)
+# --------------------------------------------------------------------------------------------------
+def lstm_workspace(T: int, B: int, I: int, H: int, D: int, device) -> torch.Tensor:
+    n = _lib.lib().rnnt_hip_lstm_workspace_bytes(T, B, I, H, D)
+    if n == 0:
+        raise RnntHipError(f"LSTM configuration not supported by the HIP kernels: T={T} B={B} I={I} H={H} D={D} "
+                           "(need H % 4 == 0, 1 <= B <= 64, D in {1,2})")
+    return torch.empty(n, device=device, dtype=torch.uint8)
+
+
+def _fill_lstm_desc(d: LstmDesc, T, B, I, H, D, lens, x, weights, y, y_drop, p, seed, gates, cst, ws) -> None:
+    d.T, d.B, d.I, d.H, d.D = T, B, I, H, D
+    d.lens = _addr(lens)
+    d.x = _addr(x)
+    d.x_st, d.x_sb = B * I, I
+    for k in range(D):
+        w_ih, w_hh, b_ih, b_hh = weights[4 * k:4 * k + 4]
+        d.w_ih[k], d.w_hh[k], d.b_ih[k], d.b_hh[k] = _addr(w_ih), _addr(w_hh), _addr(b_ih), _addr(b_hh)
+    d.y = _addr(y)
+    d.y_drop = _addr(y_drop)
+    d.dropout_p = float(p)
+    d.dropout_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    d.gates = _addr(gates)
+    d.cst = _addr(cst)
+    d.workspace = _addr(ws)
+    d.workspace_bytes = ws.numel()
+
+
+class LstmStackFn(torch.autograd.Function):
+    """x (T,B,I) time-major, lens (B) int32 on device -> y (T,B,D*H); zero rows for t >= lens[b]."""
+
+    @staticmethod
+    def forward(ctx, x, lens, hidden, num_layers, bidirectional, dropout_p, seed, *weights):
+        _need_gpu(x, lens, *weights)
+        if lens.dtype != torch.int32:
+            raise ValueError(f"lengths must be int32 (dataloader.py:23-24), got {lens.dtype}")
+        x = _f32c(x, "x")
+        weights = [_f32c(w, "lstm weight") for w in weights]
+        T, B, I0 = x.shape
+        D = 2 if bidirectional else 1
+        H = hidden
+        if B > 64:
+            raise RnntHipError("per-GPU batch > 64 is not supported by the persistent LSTM kernel in this version")
+        dev = x.device
+        ws = lstm_workspace(T, B, max(I0, D * H), H, D, dev)
+        saved = []
+        cur = x
+        for layer in range(num_layers):
+            I = cur.shape[-1]
+            wl = weights[4 * D * layer:4 * D * (layer + 1)]
+            gates = torch.empty(T, B, D * 4 * H, device=dev, dtype=torch.float32)
+            cst = torch.empty(D * T * B * H, device=dev, dtype=torch.float32)
+            y = torch.empty(T, B, D * H, device=dev, dtype=torch.float32)
+            p = dropout_p if layer < num_layers - 1 else 0.0
+            y_drop = torch.empty_like(y) if p > 0 else None
+            d = LstmDesc()
+            _fill_lstm_desc(d, T, B, I, H, D, lens, cur, wl, y, y_drop, p, seed + layer, gates, cst, ws)
+            check(_lib.lib().rnnt_hip_lstm_fwd(C.byref(d), _stream()), "rnnt_hip_lstm_fwd")
+            saved.append((cur, y, gates, cst, p))
+            cur = y_drop if p > 0 else y
+        ctx.meta = (T, B, H, D, num_layers, seed)
+        ctx.lens = lens
+        ctx.ws = ws
+        ctx.saved = saved
+        ctx.weights = weights
+        ctx.x_needs_grad = x.requires_grad
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        T, B, H, D, L, seed = ctx.meta
+        dy = _f32c(dy, "dy")
+        weights = ctx.weights
+        grads: List[Optional[torch.Tensor]] = [None] * len(weights)
+        dx = None
+        for layer in range(L - 1, -1, -1):
+            x_l, y_l, gates, cst, p = ctx.saved[layer]
+            I = x_l.shape[-1]
+            wl = weights[4 * D * layer:4 * D * (layer + 1)]
+            bd = LstmBwdDesc()
+            _fill_lstm_desc(bd.f, T, B, I, H, D, ctx.lens, x_l, wl, y_l, y_l if p > 0 else None, p, seed + layer, gates,
+                            cst, ctx.ws)
+            bd.dy = _addr(dy)
+            need_dx = layer > 0 or ctx.x_needs_grad
+            dx = torch.empty(T, B, I, device=dy.device, dtype=torch.float32) if need_dx else None
+            bd.dx = _addr(dx)
+            for k in range(D):
+                dw_ih = torch.empty_like(wl[4 * k])
+                dw_hh = torch.empty_like(wl[4 * k + 1])
+                db = torch.empty_like(wl[4 * k + 2])
+                bd.dw_ih[k], bd.dw_hh[k], bd.db[k] = _addr(dw_ih), _addr(dw_hh), _addr(db)
+                base = 4 * D * layer + 4 * k
+                grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dw_ih, dw_hh, db, db
+            check(_lib.lib().rnnt_hip_lstm_bwd(C.byref(bd), _stream()), "rnnt_hip_lstm_bwd")
+            dy = dx
+        ctx.saved = None  # release the stash
+        return (dx if ctx.x_needs_grad else None, None, None, None, None, None, None, *grads)
+
+
+def lstm_check(ws: torch.Tensor) -> None:
+    """Raises if a persistent LSTM kernel abandoned an inter-workgroup wait (synchronises the stream)."""
+    check(_lib.lib().rnnt_hip_lstm_check(_addr(ws), _stream()), "rnnt_hip_lstm_check")
+
+
+# --------------------------------------------------------------------------------------------------
+# fused joint + RNN-T loss  (replaces transducer.py:54-69 + model.py:39,57)
+# --------------------------------------------------------------------------------------------------
+def _joint_ac(enc, dec, W, Oe, Od, V):
+    """A (T,B,V) = gelu(enc) W[:, :Oe]^T ; C (U1,B,V) = gelu(dec) W[:, Oe:]^T  (two small GEMMs, GELU on load)."""
+    T, B = enc.shape[:2]
+    U1 = dec.shape[0]
+    A = torch.empty(T, B, V, device=enc.device, dtype=torch.float32)
+    Cm = torch.empty(U1, B, V, device=enc.device, dtype=torch.float32)
+    gemm(T * B, V, Oe, enc, W, A, b_sn=Oe + Od, b_sk=1, flags=GEMM_GELU_A)
+    gemm(U1 * B, V, Od, dec, W, Cm, b_off=Oe, b_sn=Oe + Od, b_sk=1, flags=GEMM_GELU_A)
+    return A, Cm
+
+
+def _joint_backward(enc, dec, W, dA, dC, needs):
+    """d_enc, d_dec, dW, db from dA (T,B,V), dC (U1,B,V)."""
+    T, B, Oe = enc.shape
+    U1, _, Od = dec.shape
+    V = W.shape[0]
+    O = Oe + Od
+    d_enc = d_dec = dW = db = None
+    if needs[0]:
+        d_enc = torch.empty_like(enc)
+        gemm(T * B, Oe, V, dA, W, d_enc, b_sn=1, b_sk=O, aux=enc, flags=GEMM_MUL_DGELU)
+    if needs[1]:
+        d_dec = torch.empty_like(dec)
+        gemm(U1 * B, Od, V, dC, W, d_dec, b_off=Oe, b_sn=1, b_sk=O, aux=dec, flags=GEMM_MUL_DGELU)
+    if needs[2]:
+        dW = torch.empty_like(W)
+        gemm(V, Oe, T * B, dA, enc, dW, a_mc=True, a_sk=V, b_sn=1, b_sk=Oe, c_div=1, c_so=O, c_si=0, flags=GEMM_GELU_B)
+        gemm(V, Od, U1 * B, dC, dec, dW, a_mc=True, a_sk=V, b_sn=1, b_sk=Od, c_off=Oe, c_div=1, c_so=O, c_si=0,
+             flags=GEMM_GELU_B)
+    if needs[3]:
+        db = colsum(dA, T * B, V)
+    return d_enc, d_dec, dW, db
+
+
+class JointLossFn(torch.autograd.Function):
+    """enc (T,B,Oe), dec (U1,B,Od) time-major -> per-utterance NLL (B,).  Never builds (B,T,U1,V)."""
+
+    @staticmethod
+    def forward(ctx, enc, dec, W, bias, labels, t_lens, u_lens, blank):
+        _need_gpu(enc, dec, W, bias, labels, t_lens, u_lens)
+        enc, dec, W, bias = _f32c(enc, "enc"), _f32c(dec, "dec"), _f32c(W, "fc.weight"), _f32c(bias, "fc.bias")
+        for name, t in (("targets", labels), ("frame lengths", t_lens), ("target lengths", u_lens)):
+            if t.dtype != torch.int32:
+                raise ValueError(f"{name} must be int32 (dataloader.py:21-24), got {t.dtype}")
+        labels = labels.contiguous()
+        T, B, Oe = enc.shape
+        U1, B2, Od = dec.shape
+        V = W.shape[0]
+        if B2 != B or W.shape[1] != Oe + Od or labels.shape != (B, U1 - 1):
+            raise ValueError(f"shape mismatch: enc {tuple(enc.shape)} dec {tuple(dec.shape)} fc {tuple(W.shape)} "
+                             f"targets {tuple(labels.shape)}")
+        A, Cm = _joint_ac(enc, dec, W, Oe, Od, V)
+        nll = torch.empty(B, device=enc.device, dtype=torch.float32)
+        dA, dC = torch.empty_like(A), torch.empty_like(Cm)
+        nws = _lib.lib().rnnt_hip_joint_loss_workspace_bytes(B, T, U1, V)
+        ws = torch.empty(nws, device=enc.device, dtype=torch.uint8)
+        check(_lib.lib().rnnt_hip_joint_loss_fwd_bwd(_addr(A), V, B * V, _addr(Cm), V, B * V, _addr(bias), _addr(labels),
+                                                     _addr(t_lens), _addr(u_lens), B, T, U1, V, int(blank), 1.0,
+                                                     _addr(nll), _addr(dA), _addr(dC), _addr(ws), nws, _stream()),
+              "rnnt_hip_joint_loss_fwd_bwd")
+        ctx.save_for_backward(enc, dec, W, dA, dC)
+        return nll
+
+    @staticmethod
+    def backward(ctx, g):
+        enc, dec, W, dA, dC = ctx.saved_tensors
+        gb = g.to(torch.float32).view(1, -1, 1)
+        dA = dA * gb  # per-utterance upstream gradient (1/B for reduction="mean", model.py:39)
+        dC = dC * gb
+        d_enc, d_dec, dW, db = _joint_backward(enc, dec, W, dA, dC, ctx.needs_input_grad[:4])
+        return d_enc, d_dec, dW, db, None, None, None, None
+
+
+class JointLogitsFn(torch.autograd.Function):
+    """Materialising joint for RNNTransducer.forward() (model.py:47-50): logits (B,T,U1,V)."""
+
+    @staticmethod
+    def forward(ctx, enc, dec, W, bias):
+        _need_gpu(enc, dec, W, bias)
+        enc, dec, W, bias = _f32c(enc, "enc"), _f32c(dec, "dec"), _f32c(W, "fc.weight"), _f32c(bias, "fc.bias")
+        T, B, Oe = enc.shape
+        U1, _, Od = dec.shape
+        V = W.shape[0]
+        A, Cm = _joint_ac(enc, dec, W, Oe, Od, V)
+        logits = torch.empty(B, T, U1, V, device=enc.device, dtype=torch.float32)
+        check(_lib.lib().rnnt_hip_joint_logits_fwd(_addr(A), V, B * V, _addr(Cm), V, B * V, _addr(bias), B, T, U1, V,
+                                                   _addr(logits), _stream()), "rnnt_hip_joint_logits_fwd")
+        ctx.save_for_backward(enc, dec, W)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        enc, dec, W = ctx.saved_tensors
+        # compatibility path only (the fused training_step never comes here): two axis sums by torch
+        dA = dlogits.sum(dim=2).transpose(0, 1).contiguous()   # (T,B,V)
+        dC = dlogits.sum(dim=1).transpose(0, 1).contiguous()   # (U1,B,V)
+        return _joint_backward(enc, dec, W, dA, dC, ctx.needs_input_grad[:4])
+
+
+class RnntLossFromLogitsFn(torch.autograd.Function):
+    """warp-transducer-shaped loss on dense logits (model.py:39,57) -> per-utterance NLL (B,)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, t_lens, u_lens, blank):
+        _need_gpu(logits, targets, t_lens, u_lens)
+        logits = _f32c(logits, "logits")
+        for name, t in (("targets", targets), ("logit lengths", t_lens), ("target lengths", u_lens)):
+            if t.dtype != torch.int32:
+                raise ValueError(f"{name} must be int32, got {t.dtype}")
+        B, T, U1, V = logits.shape
+        if targets.shape != (B, U1 - 1):
+            raise ValueError(f"targets must be (B, U) = ({B}, {U1 - 1}), got {tuple(targets.shape)}")
+        targets = targets.contiguous()
+        nll = torch.empty(B, device=logits.device, dtype=torch.float32)
+        grad = torch.empty_like(logits) if logits.requires_grad else None
+        nws = _lib.lib().rnnt_hip_joint_loss_workspace_bytes(B, T, U1, V)
+        ws = torch.empty(nws, device=logits.device, dtype=torch.uint8)
+        check(_lib.lib().rnnt_hip_loss_from_logits_fwd_bwd(_addr(logits), _addr(targets), _addr(t_lens), _addr(u_lens), B, T,
+                                                           U1, V, int(blank), 1.0, _addr(nll), _addr(grad), _addr(ws), nws,
+                                                           _stream()), "rnnt_hip_loss_from_logits_fwd_bwd")
+        ctx.grad = grad
+        return nll
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        ctx.grad = None
+        return grad * g.to(torch.float32).view(-1, 1, 1, 1), None, None, None, None

@@ -1,0 +1,67 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/rnnt_hip.h declares; the python surface mirrors the reference's names; no compute calls here."""
+import ctypes
+import os
+import re
+from argparse import Namespace
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rnntransducer_amd import _lib
+    from rnntransducer_amd.csrc import build
+    build.build()
+    header = open(os.path.join(ROOT, "include", "rnnt_hip.h")).read()
+    declared = set(re.findall(r"\b(rnnt_hip_\w+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in rnnt_hip.h but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert _lib.lib().rnnt_hip_version() == 1
+
+
+def test_argument_validation_happens_before_any_device_work():
+    from rnntransducer_amd import _lib
+    L = _lib.lib()
+    assert L.rnnt_hip_gemm_f32(None, None) == -1 and b"null" in L.rnnt_hip_last_error()
+    assert L.rnnt_hip_joint_loss_workspace_bytes(0, 1, 1, 1) == 0
+    assert L.rnnt_hip_joint_loss_workspace_bytes(2, 10, 3, 5) > 0
+    assert L.rnnt_hip_lstm_workspace_bytes(10, 2, 80, 6, 2) == 0       # H % 4 != 0 -> unsupported
+    assert L.rnnt_hip_lstm_workspace_bytes(10, 2, 80, 128, 2) > 0
+    rc = L.rnnt_hip_loss_from_logits_fwd_bwd(None, None, None, None, 1, 1, 600, 3, 0, 1.0, None, None, None, 0, None)
+    assert rc == -1
+
+
+def test_module_surface_mirrors_reference_and_fails_loudly_on_cpu():
+    from rnntransducer_amd import RNNTransducer
+    from rnntransducer_amd._lib import RnntHipError
+    args = Namespace(learning_rate=1e-3, weight_decay=1e-4, warmup_ratio=0.2, final_div_factor=1e4, total_steps=10)
+    m = RNNTransducer(dict(embedding_size=72, hidden_size=128, output_size=128, num_layers=1),
+                      dict(input_size=80, hidden_size=128, output_size=128, num_layers=1), dict(num_classes=72), args)
+    keys = set(m.state_dict())
+    for k in ("jointnet.encoder.rnn.weight_ih_l0", "jointnet.encoder.rnn.weight_hh_l0_reverse", "jointnet.encoder.out_proj.bias",
+              "jointnet.decoder.embedding.weight", "jointnet.decoder.rnn.bias_hh_l0", "jointnet.decoder.out_proj.weight",
+              "jointnet.fc.weight", "jointnet.fc.bias"):
+        assert k in keys, k
+    assert m.jointnet.fc.weight.shape == (72, 256)
+    assert torch.all(m.jointnet.decoder.embedding.weight[0] == 0)       # padding_idx row (decoder.py:69)
+    with pytest.raises(RnntHipError):                                     # no CPU / eager fallback
+        m(torch.zeros(2, 5, 80), [5, 4], torch.zeros(2, 3, dtype=torch.long), [3, 2])
+    with pytest.raises(NotImplementedError):
+        RNNTransducer(dict(embedding_size=72, hidden_size=128, output_size=128, num_layers=1),
+                      dict(input_size=80, hidden_size=128, output_size=128, num_layers=1, rnn_type="gru"), dict(num_classes=72), args)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "rnntransducer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                hit = re.search(r"^\s*(from|import)\s+oracle|oracle[/.]\w|librnnt_oracle", src, re.M)
+                assert hit is None, f"{f} reaches into oracle/: {hit.group(0)!r}"

@@ -1,0 +1,91 @@
+"""rnnt_hip_gemm_f32 (f32-input MFMA) vs a float64 CPU product: every operand map the hot path uses."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-5  # fp32 fma chains over K <= 4096 against an fp64 reference, relative to sum |a||b|
+
+
+def _ref_check(out, ref, scale):
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= RTOL * scale, f"max err {err} vs budget {RTOL * scale}"
+
+
+def gelu64(x):
+    return torch.nn.functional.gelu(x.double(), approximate="tanh")
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (130, 70, 33), (257, 129, 80), (512, 256, 1024), (1000, 72, 512), (64, 2048, 640),
+                                   (37, 10, 16), (5, 3, 7)])
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_gemm_modes(M, N, K, mode):
+    from rnntransducer_amd.ops import gemm
+    g = torch.Generator().manual_seed(M * 31 + N * 7 + K)
+    dev = "cuda"
+    if mode == "nt":      # C = A (M,K) . W (N,K)^T + bias   (forward projections)
+        A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        out = torch.full((M, N), float("nan"), device=dev)
+        gemm(M, N, K, A.to(dev), W.to(dev), out, bias=bias.to(dev))
+        ref = A.double() @ W.double().T + bias.double()
+        scale = (A.abs().double() @ W.abs().double().T).max().item()
+    elif mode == "nn":    # C = G (M,K) . W (K,N)            (dX = dG . W)
+        A, W = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+        out = torch.full((M, N), float("nan"), device=dev)
+        gemm(M, N, K, A.to(dev), W.to(dev), out, b_sn=1, b_sk=N)
+        ref = A.double() @ W.double()
+        scale = (A.abs().double() @ W.abs().double()).max().item()
+    else:                 # C = G (K,M)^T . X (K,N)          (dW = dG^T . X)
+        A, W = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+        out = torch.full((M, N), float("nan"), device=dev)
+        gemm(M, N, K, A.to(dev), W.to(dev), out, a_mc=True, a_sk=M, b_sn=1, b_sk=N)
+        ref = A.double().T @ W.double()
+        scale = (A.abs().double().T @ W.abs().double()).max().item()
+    _ref_check(out, ref, scale)
+
+
+def test_gemm_row_maps_gelu_and_epilogues():
+    from rnntransducer_amd._lib import GEMM_ACCUM, GEMM_GELU_A, GEMM_GELU_B, GEMM_MUL_DGELU
+    from rnntransducer_amd.ops import gemm
+    g = torch.Generator().manual_seed(5)
+    dev = "cuda"
+    T, B, K, N = 9, 5, 24, 40
+    x_bm = torch.randn(B, T, K, generator=g)                      # batch-major source read as rows (t,b)
+    W = torch.randn(N, K, generator=g)
+    out = torch.zeros(T * B, N, device=dev)
+    gemm(T * B, N, K, x_bm.to(dev), W.to(dev), out, a_div=B, a_so=K, a_si=T * K, flags=GEMM_GELU_A)
+    ref = gelu64(x_bm.transpose(0, 1).reshape(T * B, K)) @ W.double().T
+    _ref_check(out, ref, 40.0)
+    # rows (t,b) scattered back into a batch-major destination + ACCUM
+    dst = torch.ones(B, T, N, device=dev)
+    gemm(T * B, N, K, x_bm.transpose(0, 1).contiguous().to(dev), W.to(dev), dst, c_div=B, c_so=N, c_si=T * N, flags=GEMM_ACCUM)
+    ref2 = (x_bm.double() @ W.double().T) + 1.0
+    _ref_check(dst, ref2, 40.0)
+    # gathered rows (embedding-style) via a_rowidx
+    table = torch.randn(11, K, generator=g)
+    idx = torch.randint(0, 11, (T * B,), generator=g)
+    out3 = torch.zeros(T * B, N, device=dev)
+    gemm(T * B, N, K, table.to(dev), W.to(dev), out3, a_rowidx=idx.to(dev), a_si=K)
+    _ref_check(out3, table[idx].double() @ W.double().T, 40.0)
+    # GELU on B + sub-block destination (dW_e / dW_d halves of fc.weight's gradient)
+    dA = torch.randn(T * B, N, generator=g)
+    enc = torch.randn(T * B, K, generator=g)
+    dW = torch.zeros(N, K + 8, device=dev)
+    gemm(N, K, T * B, dA.to(dev), enc.to(dev), dW, a_mc=True, a_sk=N, b_sn=1, b_sk=K, c_off=8, c_div=1, c_so=K + 8, c_si=0,
+         flags=GEMM_GELU_B)
+    _ref_check(dW[:, 8:], dA.double().T @ gelu64(enc), 60.0)
+    assert torch.all(dW[:, :8] == 0)
+    # epilogue x gelu'(aux)
+    d_enc = torch.zeros(T * B, K, device=dev)
+    Wk = torch.randn(N, K, generator=g)
+    gemm(T * B, K, N, dA.to(dev), Wk.to(dev), d_enc, b_sn=1, b_sk=K, aux=enc.to(dev), flags=GEMM_MUL_DGELU)
+    e = enc.double().requires_grad_(True)
+    gelu64(e).backward(dA.double() @ Wk.double())
+    _ref_check(d_enc, e.grad, 60.0)
+
+
+def test_gemm_rejects_bad_arguments():
+    from rnntransducer_amd.ops import gemm
+    a = torch.zeros(4, 4, device="cuda")
+    with pytest.raises(ValueError):
+        gemm(4, 4, 4, a, a, a, b_sn=2, b_sk=2)

