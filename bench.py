@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — utterances/sec of the full RNN-T training step on the MI355X HIP hot path.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                (N>1, one rank per GPU, RCCL over xGMI)
+
+A "step" = forward (LSTM encoder + LSTM prediction net) + fused joint/RNN-T loss + backward + flat-gradient
+all-reduce + AdamW, on one synthetic batch that is already resident in HBM.  Workload at every N: BASELINE.json
+configs[1] per GPU — B=32, T=1000 (10 s @ 80 mel), U=40, V=72, 4x512 bi-LSTM encoder / 1x512 LSTM prediction net,
+fp32, inter-layer dropout 0.2.  Weak scaling: per-GPU work fixed; value = total utterances / s.
+
+Rank 0 prints ONE JSON line with the driver's contract plus
+  "roofline"     for the kernel that took the most time inside the timed region (live HIP-event timing from the
+                 library's opt-in profiler; algorithmic FLOPs/bytes per launch are computed in the launch wrappers),
+  "cpu_baseline" the CPU oracle (torch-CPU composite of the reference path + C loss) timed on this box's host cores
+                 on a bounded sample, N=1 only,
+  "loss_rel_delta" |L_hip - L_oracle| / L_oracle on that same sample (dropout off on both sides).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # name: (B, T, U, V, enc(H, L), pred(H, L), O)
+    "c1": (2, 100, 20, 72, (128, 1), (128, 1), 128),
+    "c2": (32, 1000, 40, 72, (512, 4), (512, 1), 512),
+    "c3": (8, 2000, 120, 72, (512, 4), (512, 1), 512),
+    "c5": (16, 1500, 80, 2048, (640, 6), (640, 1), 640),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+
+
+def build_model(cfg, dropout, total_steps):
+    from argparse import Namespace
+
+    from rnntransducer_amd import RNNTransducer
+    B, T, U, V, (He, Le), (Hp, Lp), O = cfg
+    tn = dict(input_size=80, hidden_size=He, output_size=O, num_layers=Le, rnn_type="lstm", dropout=dropout, bidirectional=True)
+    pn = dict(embedding_size=V, hidden_size=Hp, output_size=O, num_layers=Lp, rnn_type="lstm", dropout=dropout)
+    args = Namespace(learning_rate=1e-3, weight_decay=1e-4, warmup_ratio=0.2, final_div_factor=1e4, total_steps=total_steps,
+                     move_metrics_to_cpu=False)
+    torch.manual_seed(0)  # same initial weights on every rank (DDP broadcasts rank 0's; same seed is equivalent)
+    return RNNTransducer(pn, tn, dict(num_classes=V), args), tn, pn
+
+
+def cpu_baseline(model, tn, pn, V, batch, sample_b, threads):
+    """The oracle's full training step on `sample_b` utterances of the same workload, on host cores."""
+    from oracle.rnnt_oracle import OracleJointNet, training_loss
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    oracle = OracleJointNet(dict(tn, dropout=0.0), dict(pn, pad_token_id=0, dropout=0.0), V)
+    oracle.load_state_dict({k[len("jointnet."):]: v.detach().cpu() for k, v in model.state_dict().items()})
+    opt = torch.optim.AdamW(oracle.parameters(), lr=1e-3, weight_decay=1e-4)
+    sub = tuple((x[:sample_b].cpu() if isinstance(x, torch.Tensor) else x[:sample_b]) for x in batch)
+    t0 = time.perf_counter()
+    loss = training_loss(oracle, sub)
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return sample_b / dt, float(loss), dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=list(CONFIGS))
+    ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--ragged", action="store_true", help="KsponSpeech-shaped ragged lengths (SURVEY §8d c4 variant)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists in rnntransducer_amd)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rnntransducer_amd import _lib
+    from rnntransducer_amd.data import synthetic_batch
+    from rnntransducer_amd.dist import FlatGradAllReduce
+
+    cfg = CONFIGS[a.config]
+    B, T, U, V = cfg[:4]
+    model, tn, pn = build_model(cfg, a.dropout, a.warmup + a.steps + 1)
+    model = model.to(dev).train()
+    batch = synthetic_batch(B, T, U, V, ragged=a.ragged, seed=1234 + rank, device=dev)
+    conf = model.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    flat = FlatGradAllReduce(model.parameters())
+
+    def step():
+        flat.zero()
+        loss = model.training_step(batch, 0)["loss"]
+        loss.backward()
+        flat.all_reduce()
+        opt.step()
+        sched.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    L = _lib.lib()
+    L.rnnt_hip_prof_enable(1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    L.rnnt_hip_prof_enable(0)
+    last_loss = float(loss)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # per-kernel totals over the timed region (HIP events on the launch stream, recorded inside the library)
+    nk = len(_lib.KERNEL_KINDS)
+    ms = (ctypes.c_double * nk)()
+    work = (ctypes.c_double * nk)()
+    cnt = (ctypes.c_int64 * nk)()
+    _lib.check(L.rnnt_hip_prof_collect(ms, work, cnt, nk), "prof_collect")
+    kernels = {}
+    for i, name in enumerate(_lib.KERNEL_KINDS):
+        if cnt[i]:
+            kernels[name] = {"launches": int(cnt[i]), "ms_total": round(ms[i], 3), "avg_us": round(1e3 * ms[i] / cnt[i], 2),
+                             "work_per_launch": work[i] / cnt[i]}
+    dom = max((k for k in kernels if k != "misc"), key=lambda k: kernels[k]["ms_total"])
+    kd = kernels[dom]
+    per_launch_s = kd["ms_total"] / kd["launches"] / 1e3
+    if dom == "gemm_f32_kernel":
+        achieved = kd["work_per_launch"] / per_launch_s / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None}
+    else:
+        achieved = kd["work_per_launch"] / per_launch_s / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None}
+    roof["avg_launch_us"] = kd["avg_us"]
+    roof["launches"] = kd["launches"]
+
+    out = {
+        "metric": "utterances/sec", "value": round(world * B * a.steps / dt, 3), "unit": "utt/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{list(CONFIGS).index(a.config)}] {a.config}: full train step, B={B}/GPU T={T} "
+                               f"(10 ms frames x 80 mel) U={U} V={V}, enc {cfg[4][1]}x{cfg[4][0]} bi-LSTM, pred {cfg[5][1]}x{cfg[5][0]} LSTM, "
+                               f"O={cfg[6]}, dropout {a.dropout}, {'ragged' if a.ragged else 'fixed'} lengths",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "grad_allreduce_bytes": flat.bytes()},
+        "last_loss": round(last_loss, 4), "roofline": roof, "kernels": kernels,
+    }
+
+    if world == 1 and not a.no_cpu_baseline:
+        # loss parity on the sample: HIP with dropout off vs the oracle (same weights, same utterances)
+        nb = min(a.cpu_sample, B)
+        model.eval()
+        with torch.no_grad():
+            sub = tuple((x[:nb] if isinstance(x, torch.Tensor) else x[:nb]) for x in batch)
+            # weights moved during the timed steps: compare on the CURRENT weights
+            hip_loss = float(model.jointnet.loss(sub[0], sub[2], sub[3], sub[5], sub[6], model.blank_token_id).mean())
+        model.train()
+        v, oracle_loss, secs = cpu_baseline(model, tn, pn, V, batch, nb, a.cpu_threads)
+        out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": a.cpu_threads, "kind": "port",
+                               "sample": f"1 full train step (fwd+RNN-T loss+bwd+AdamW) of the oracle on {nb} utterances of the same "
+                                         f"workload, {secs:.1f} s, torch.set_num_threads({a.cpu_threads})"}
+        out["loss_rel_delta"] = abs(hip_loss - oracle_loss) / abs(oracle_loss)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / v, 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,25 @@ const char* rnnt_hip_last_error(void);
 int rnnt_hip_device_cus(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * Opt-in live profiler (used by bench.py only).  While enabled, every kernel launch below is bracketed by two
+ * HIP events recorded on the launch stream; collect() synchronises on them, sums elapsed ms / algorithmic work /
+ * launch counts per kernel kind, and resets.  This is the only global state in the library, off by default.
+ * `work` unit: FLOPs for RNNT_K_GEMM, algorithmic bytes for all other kinds.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  RNNT_K_GEMM = 0,       /* gemm_f32_kernel                                   */
+  RNNT_K_LSTM_FWD = 1,   /* lstm_fwd_kernel (persistent recurrence)           */
+  RNNT_K_LSTM_BWD = 2,   /* lstm_bwd_kernel                                   */
+  RNNT_K_LSE = 3,        /* lse_sep_kernel / lse_dense_kernel                 */
+  RNNT_K_ALPHABETA = 4,  /* alphabeta_kernel                                  */
+  RNNT_K_LATGRAD = 5,    /* grad_sep_kernel / grad_dense_kernel + reduce_dc   */
+  RNNT_K_MISC = 6,       /* permutes, column sums, embedding, logits          */
+  RNNT_K_COUNT = 7
+};
+int rnnt_hip_prof_enable(int on);
+int rnnt_hip_prof_collect(double* ms, double* work, int64_t* count, int nkinds);
+
+/* ------------------------------------------------------------------------------------------------
  * Dense fp32 GEMM on f32-input MFMA (v_mfma_f32_32x32x2_f32):  C = op(A) . op(B) (+ bias)
  * Replaces the BLAS calls behind nn.Linear / the hoisted LSTM input projection:
  *   networks/encoder.py:76,103 (out_proj), networks/decoder.py:80,124 (out_proj),

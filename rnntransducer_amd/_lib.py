@@ -44,6 +44,8 @@ SYMBOLS = {
     "rnnt_hip_version": (C.c_int, []),
     "rnnt_hip_last_error": (C.c_char_p, []),
     "rnnt_hip_device_cus": (C.c_int, []),
+    "rnnt_hip_prof_enable": (C.c_int, [C.c_int]),
+    "rnnt_hip_prof_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "rnnt_hip_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "rnnt_hip_lstm_workspace_bytes": (C.c_size_t, [c_i32] * 5),
     "rnnt_hip_lstm_fwd": (C.c_int, [C.POINTER(LstmDesc), C.c_void_p]),
@@ -62,6 +64,9 @@ SYMBOLS = {
     "rnnt_hip_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p]),
     "rnnt_hip_embedding_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, c_i64, C.c_void_p, C.c_void_p]),
 }
+
+KERNEL_KINDS = ["gemm_f32_kernel", "lstm_fwd_kernel", "lstm_bwd_kernel", "lse_kernel", "alphabeta_kernel",
+                "lattice_grad_kernel", "misc"]
 
 _lib = None
 

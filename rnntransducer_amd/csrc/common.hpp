@@ -30,6 +30,17 @@ void set_error(const char* fmt, ...);
 
 #define RNNT_CHECK_LAUNCH() RNNT_CHECK_HIP(hipGetLastError())
 
+// Opt-in profiler scope (api.hip): when rnnt_hip_prof_enable(1) was called, brackets the enclosed launches with
+// HIP events on `s`; `work` is the algorithmic FLOPs (GEMM) or bytes (everything else) of the launch.
+struct ProfScope {
+  ProfScope(int kind, double work, hipStream_t s);
+  ~ProfScope();
+  int kind_;
+  double work_;
+  hipStream_t stream_;
+  void* start_;
+};
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

@@ -264,6 +264,7 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   const int tiles = (int)(ceil_div(d->M, BM) * ceil_div(d->N, BN));
   dim3 grid(tiles), block(256);
   hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(RNNT_K_GEMM, 2.0 * (double)d->M * (double)d->N * (double)d->K, s);
 #define LAUNCH(AK, BKC, V) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, V>), grid, block, 0, s, k)
   if (a_kc && b_kc) { if (vec) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
   else if (a_kc && !b_kc) { if (vec) LAUNCH(true, false, true); else LAUNCH(true, false, false); }

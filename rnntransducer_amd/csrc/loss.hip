@@ -435,6 +435,7 @@ int check_common(const void* labels, const void* t_lens, const void* u_lens, int
 
 int launch_alphabeta(const LossWs& w, const int* t_lens, const int* u_lens, int B, int T, int U1, hipStream_t s) {
   const int K = (int)ceil_div(U1, 64);
+  ProfScope prof(RNNT_K_ALPHABETA, 2.0 * (8.0 + 8.0) * (double)B * T * U1, s);  // read blk+emit, write alpha|beta (fp64)
   dim3 grid(B, 2), block(64);
 #define AB(KK) hipLaunchKernelGGL((alphabeta_kernel<KK>), grid, block, 0, s, w.blk, w.emit, t_lens, u_lens, T, U1, w.alpha, w.beta, w.ll)
   switch (K) {
@@ -472,8 +473,12 @@ extern "C" int rnnt_hip_joint_loss_fwd_bwd(const float* A, int64_t a_sb, int64_t
   hipStream_t s = (hipStream_t)stream;
   const int ntiles = (int)ceil_div(T, TT);
 
+  const double cells = (double)B * T * U1;
+  {
+  ProfScope prof(RNNT_K_LSE, 4.0 * ((double)B * T * V + (double)B * U1 * V) + 8.0 * cells, s);
   hipLaunchKernelGGL(lse_sep_kernel, dim3(ntiles, (unsigned)ceil_div(U1, LSE_UT), B), dim3(256), 0, s, A, C, bias, labels,
                      T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, w.blk, w.emit);
+  }
   RNNT_CHECK_LAUNCH();
   if (int rc = launch_alphabeta(w, t_lens, u_lens, B, T, U1, s)) return rc;
   hipLaunchKernelGGL(nll_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, w.ll, B, nll);
@@ -483,6 +488,7 @@ extern "C" int rnnt_hip_joint_loss_fwd_bwd(const float* A, int64_t a_sb, int64_t
     RNNT_CHECK_ARG(lds <= 160 * 1024, "joint_loss: U+1 = %d needs %zu B of LDS (> 160 KiB)", U1, lds);
     if (lds > 64 * 1024)
       RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)grad_sep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(RNNT_K_LATGRAD, 4.0 * 2.0 * ((double)B * T * V + (double)B * U1 * V) + 24.0 * cells, s);
     hipLaunchKernelGGL(grad_sep_kernel, dim3(ntiles, B), dim3(256), lds, s, A, C, bias, labels, t_lens, u_lens, w.blk,
                        w.emit, w.alpha, w.beta, w.ll, T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, gscale, dA, w.dCp);
     RNNT_CHECK_LAUNCH();
@@ -501,6 +507,7 @@ extern "C" int rnnt_hip_joint_logits_fwd(const float* A, int64_t a_sb, int64_t a
   RNNT_CHECK_ARG(B >= 1 && T >= 1 && U1 >= 1 && V >= 1, "joint_logits: dims must be positive");
   const long total = (long)B * T * U1 * V;
   const unsigned grid = (unsigned)(ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536);
+  ProfScope prof(RNNT_K_MISC, 4.0 * (double)total, (hipStream_t)stream);
   hipLaunchKernelGGL(joint_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A, C, bias, T, U1, V, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, total, logits);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
@@ -517,12 +524,16 @@ extern "C" int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int3
   hipStream_t s = (hipStream_t)stream;
   const long ncell = (long)B * T * U1;
   const unsigned grid = (unsigned)(ceil_div(ncell, 4) < 16384 ? ceil_div(ncell, 4) : 16384);
+  {
+  ProfScope prof(RNNT_K_LSE, 4.0 * (double)ncell * V + 8.0 * (double)ncell, s);
   hipLaunchKernelGGL(lse_dense_kernel, dim3(grid), dim3(256), 0, s, logits, labels, B, T, U1, V, blank, w.blk, w.emit);
+  }
   RNNT_CHECK_LAUNCH();
   if (int rc = launch_alphabeta(w, t_lens, u_lens, B, T, U1, s)) return rc;
   hipLaunchKernelGGL(nll_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, w.ll, B, nll);
   RNNT_CHECK_LAUNCH();
   if (grad) {
+    ProfScope prof(RNNT_K_LATGRAD, 8.0 * (double)ncell * V + 24.0 * (double)ncell, s);
     hipLaunchKernelGGL(grad_dense_kernel, dim3(grid), dim3(256), 0, s, logits, labels, t_lens, u_lens, w.blk, w.emit,
                        w.alpha, w.beta, w.ll, B, T, U1, V, blank, gscale, grad);
     RNNT_CHECK_LAUNCH();

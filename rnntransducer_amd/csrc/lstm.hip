@@ -538,7 +538,13 @@ int launch_persistent(K kernel, const LstmK& k, const Plan& pl, size_t lds, hipS
     set_error("%s: %d workgroups cannot be co-resident (%d CUs x %d per CU)", what, k.D * k.NC, cus, per_cu);
     return RNNT_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(kernel, dim3(k.D * k.NC), dim3(256), lds, s, k);
+  {
+    // algorithmic bytes of the recurrence: gates read+write (4H), c (H), y or dy (H) per (t,b,d) [+ weights once]
+    const double per_tb = (k.dy ? (8.0 + 2.0 + 1.0) : (8.0 + 1.0 + 1.0)) * k.H * 4.0;
+    ProfScope prof(k.dy ? RNNT_K_LSTM_BWD : RNNT_K_LSTM_FWD,
+                   per_tb * k.T * k.B * k.D + 4.0 * 4.0 * k.H * k.H * k.D, s);
+    hipLaunchKernelGGL(kernel, dim3(k.D * k.NC), dim3(256), lds, s, k);
+  }
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }

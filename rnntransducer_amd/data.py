@@ -1,0 +1,36 @@
+"""Synthetic KsponSpeech-shaped batches in the reference's 7-tuple layout (dataloader.py:16-49) and the
+length-grouped rank sharding of datasampler.py:74-99 (sort by length descending, pad by wrap-around to a multiple
+of the world size, deal `indices[rank::world]`).  Recipe: SURVEY.md §8(d)."""
+from typing import List, Sequence
+
+import torch
+
+
+def synthetic_batch(B: int, T: int, U: int, V: int, n_mels: int = 80, ragged: bool = False, seed: int = 1234,
+                    blank: int = 0, device="cpu"):
+    """(input_audios f32 (B,T,n_mels), audio_lengths list, tensor_audio_lengths i32 (B,), input_texts i64 (B,U+1),
+    text_lengths list, targets i32 (B,U), target_lengths i32 (B,)) — frames beyond T_b are 0.0, labels in 1..V-1."""
+    g = torch.Generator().manual_seed(seed)
+    audios = torch.randn(B, T, n_mels, generator=g)
+    if ragged:
+        t_list = torch.randint(max(1, T // 2), T + 1, (B,), generator=g).tolist()
+        t_list[0] = T
+        u_list = [max(1, round(U * t / T)) for t in t_list]
+        u_list[0] = U
+    else:
+        t_list, u_list = [T] * B, [U] * B
+    targets = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32)
+    for b in range(B):
+        audios[b, t_list[b]:] = 0.0
+        targets[b, u_list[b]:] = blank
+    texts = torch.cat([torch.full((B, 1), blank, dtype=torch.int64), targets.to(torch.int64)], dim=1)
+    return (audios.to(device), t_list, torch.tensor(t_list, dtype=torch.int32, device=device), texts.to(device),
+            [u + 1 for u in u_list], targets.to(device), torch.tensor(u_list, dtype=torch.int32, device=device))
+
+
+def length_grouped_indices(lengths: Sequence[int], rank: int, world: int) -> List[int]:
+    """datasampler.py:74-99 behaviour: descending length, wrap-pad to a multiple of world, rank-strided deal."""
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    pad = (-len(order)) % world
+    order = order + order[:pad]
+    return order[rank::world]
