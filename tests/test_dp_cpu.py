@@ -1,0 +1,78 @@
+"""N>1 path on CPU: world_size-2 gloo run of the flat-gradient all-reduce (rnntransducer_amd/dist.py) and the
+length-grouped sharding (rnntransducer_amd/data.py), which mirror train.py:45 (DDP gradient averaging) and
+datasampler.py:74-99 (sort desc, wrap-pad, rank-strided deal)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rnntransducer_amd.data import length_grouped_indices, synthetic_batch
+from rnntransducer_amd.dist import FlatGradAllReduce
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    flat = FlatGradAllReduce(net.parameters())
+    data = torch.arange(world * 4 * 6, dtype=torch.float32).reshape(world * 4, 6) / 10.0
+    shard = data[rank * 4:(rank + 1) * 4]
+    for _ in range(2):  # second iteration checks zero() really clears the views
+        flat.zero()
+        net(shard).pow(2).mean().backward()
+        flat.all_reduce()
+    out[rank] = flat.flat.clone()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world2_equals_big_batch_average():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        g0, g1 = out[0], out[1]
+    assert torch.equal(g0, g1)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    data = torch.arange(world * 4 * 6, dtype=torch.float32).reshape(world * 4, 6) / 10.0
+    net(data).pow(2).mean().backward()  # mean over the global batch == average of per-rank means (equal shards)
+    ref = torch.cat([p.grad.flatten() for p in net.parameters()])
+    assert torch.allclose(g0, ref, atol=1e-6)
+
+
+def test_length_grouped_sharding_matches_reference_sampler_behaviour():
+    lengths = [5, 9, 3, 9, 7, 1, 8]
+    # descending by length (ties by index), wrap-padded to a multiple of world, dealt rank-strided
+    assert length_grouped_indices(lengths, 0, 2) == [1, 6, 0, 5]
+    assert length_grouped_indices(lengths, 1, 2) == [3, 4, 2, 1]
+    allidx = sorted(length_grouped_indices(lengths, 0, 3) + length_grouped_indices(lengths, 1, 3) + length_grouped_indices(lengths, 2, 3))
+    assert set(allidx) == set(range(7)) and len(allidx) == 9
+    # every rank sees a similar, descending length profile (the wrap-padded tail entry aside)
+    for r in range(3):
+        got = [lengths[i] for i in length_grouped_indices(lengths, r, 3)][:2]
+        assert got == sorted(got, reverse=True)
+
+
+def test_synthetic_batch_follows_dataloader_contract():
+    a, a_list, a_len, texts, t_list, targets, u_len = synthetic_batch(4, 50, 10, 72, ragged=True, seed=1)
+    assert a.dtype == torch.float32 and a.shape == (4, 50, 80)
+    assert a_len.dtype == torch.int32 and u_len.dtype == torch.int32 and targets.dtype == torch.int32
+    assert texts.dtype == torch.int64 and texts.shape == (4, 11) and torch.all(texts[:, 0] == 0)
+    assert isinstance(a_list, list) and isinstance(t_list, list)
+    for b in range(4):
+        assert t_list[b] == int(u_len[b]) + 1                      # dataloader.py:39-40
+        assert torch.all(a[b, a_list[b]:] == 0)                    # dataloader.py:41 pad value 0
+        assert torch.all(targets[b, :int(u_len[b])] > 0) and torch.all(targets[b, int(u_len[b]):] == 0)
+        assert torch.equal(texts[b, 1:], targets[b].long())
+    assert max(a_list) == 50 and int(u_len.max()) == 10
