@@ -87,8 +87,11 @@ typedef struct rnnt_gemm_desc {
   const float* bias; /* (N) or NULL */
   const float* aux;  /* for RNNT_GEMM_MUL_DGELU */
   uint32_t flags;
+  void* workspace;   /* optional: enables deterministic split-K (slabs + fixed-order reduce) for GEMMs whose   */
+  size_t workspace_bytes; /* output has too few tiles to fill the chip; see rnnt_hip_gemm_workspace_bytes     */
 } rnnt_gemm_desc;
 
+size_t rnnt_hip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -175,8 +178,11 @@ int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int32_t* labels
  * construction, nn.Embedding(padding_idx=blank)). */
 int rnnt_hip_embedding_fwd(const float* W, const int64_t* idx, int64_t M, int32_t H, int32_t V, float* out, void* stream);
 
-/* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients: fc.bias, out_proj.bias, LSTM biases) */
-int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream);
+/* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients: fc.bias, out_proj.bias, LSTM biases).
+ * Two-stage fixed-order reduction; workspace = rnnt_hip_colsum_workspace_bytes(M, N) bytes. */
+size_t rnnt_hip_colsum_workspace_bytes(int64_t M, int64_t N);
+int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* Embedding backward (networks/decoder.py:69,102): dW[idx[m]] += dE[m] for idx[m] != padding_idx. dW (V,H)
  * must be zeroed by the caller. */

@@ -22,7 +22,8 @@ class GemmDesc(C.Structure):
     _fields_ = [("M", c_i64), ("N", c_i64), ("K", c_i64), ("A", C.c_void_p), ("a_div", c_i64), ("a_so", c_i64),
                 ("a_si", c_i64), ("a_sk", c_i64), ("a_mc", c_i32), ("a_rowidx", C.c_void_p), ("B", C.c_void_p),
                 ("b_sn", c_i64), ("b_sk", c_i64), ("C", C.c_void_p), ("c_div", c_i64), ("c_so", c_i64),
-                ("c_si", c_i64), ("bias", C.c_void_p), ("aux", C.c_void_p), ("flags", C.c_uint32)]
+                ("c_si", c_i64), ("bias", C.c_void_p), ("aux", C.c_void_p), ("flags", C.c_uint32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class LstmDesc(C.Structure):
@@ -46,6 +47,7 @@ SYMBOLS = {
     "rnnt_hip_device_cus": (C.c_int, []),
     "rnnt_hip_prof_enable": (C.c_int, [C.c_int]),
     "rnnt_hip_prof_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "rnnt_hip_gemm_workspace_bytes": (C.c_size_t, [c_i64, c_i64, c_i64]),
     "rnnt_hip_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "rnnt_hip_lstm_workspace_bytes": (C.c_size_t, [c_i32] * 5),
     "rnnt_hip_lstm_fwd": (C.c_int, [C.POINTER(LstmDesc), C.c_void_p]),
@@ -61,7 +63,8 @@ SYMBOLS = {
                                                      c_i32, c_i32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_size_t, C.c_void_p]),
     "rnnt_hip_embedding_fwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p]),
-    "rnnt_hip_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p]),
+    "rnnt_hip_colsum_workspace_bytes": (C.c_size_t, [c_i64, c_i64]),
+    "rnnt_hip_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_embedding_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, c_i64, C.c_void_p, C.c_void_p]),
 }
 

@@ -29,6 +29,8 @@ struct GemmK {
   const float* bias;
   const float* aux;
   unsigned flags;
+  int splits, kchunk;  // split-K: blockIdx.y = split z handles k in [z*kchunk, min(K, (z+1)*kchunk))
+  float* slab;         // splits > 1: partial products go to slab[z][M][N], reduced by splitk_reduce_kernel
 };
 
 // Loads this thread's share (2 x 4 floats) of a (128 rows) x (16 k) operand tile and parks it in LDS K-major.
@@ -164,9 +166,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  const int nk = (p.K + BK - 1) / BK;
-  ta.load(0);
-  tb.load(0);
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  ta.K = tb.K = kend;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  ta.load(kbeg);
+  tb.load(kbeg);
   ta.store(As[0]);
   tb.store(Bs[0]);
   __syncthreads();
@@ -177,8 +182,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      ta.load((kt + 1) * BK);
-      tb.load((kt + 1) * BK);
+      ta.load(kbeg + (kt + 1) * BK);
+      tb.load(kbeg + (kt + 1) * BK);
     }
     const float* as = As[cur] + aoff;
     const float* bs = Bs[cur] + boff;
@@ -199,6 +204,22 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
   }
 
   // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+  if (p.splits > 1) {
+    float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+          if (n < p.N) slab[(long)m * p.N + n] = acc[i][j][v];
+        }
+      }
+    return;
+  }
   const bool accum = (p.flags & RNNT_GEMM_ACCUM) != 0, dgelu = (p.flags & RNNT_GEMM_MUL_DGELU) != 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -222,11 +243,38 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
   }
 }
 
+// fixed-order sum of the split-K slabs + the epilogue the single-pass kernel would have applied
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK p) {
+  const long total = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float s = 0.f;
+    for (int z = 0; z < p.splits; ++z) s += p.slab[(long)z * total + i];
+    if (p.bias) s += p.bias[n];
+    const long off = (long)(m / p.c_div) * p.c_so + (long)(m % p.c_div) * p.c_si + n;
+    if (p.flags & RNNT_GEMM_MUL_DGELU) s *= dgelu_tanh(p.aux[off]);
+    if (p.flags & RNNT_GEMM_ACCUM) s += p.C[off];
+    p.C[off] = s;
+  }
+}
+
 inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
 }  // namespace
 
 }  // namespace rnnt
+
+extern "C" size_t rnnt_hip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  // enough for the split count rnnt_hip_gemm_f32 would pick; 0 when it would not split
+  if (M <= 0 || N <= 0 || K < 8 * rnnt::BK) return 0;
+  const long tiles = rnnt::ceil_div(M, rnnt::BM) * rnnt::ceil_div(N, rnnt::BN);
+  if (tiles >= 512) return 0;
+  long want = rnnt::ceil_div(1024, tiles);
+  const long by_k = K / (8 * rnnt::BK);
+  if (want > by_k) want = by_k;
+  if (want > 64) want = 64;
+  return want >= 2 ? (size_t)want * M * N * 4 : 0;
+}
 
 extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   using namespace rnnt;
@@ -262,7 +310,23 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   else vec = vec && (d->b_sk % 4 == 0);
 
   const int tiles = (int)(ceil_div(d->M, BM) * ceil_div(d->N, BN));
-  dim3 grid(tiles), block(256);
+  // split-K when the output has too few tiles to fill 256 CUs and K is deep (weight-gradient GEMMs):
+  // partial slabs in the caller's workspace, summed in fixed order (bitwise reproducible; no float atomics)
+  int splits = 1;
+  if (d->workspace && tiles < 512 && d->K >= 8 * BK) {
+    long want = ceil_div(1024, tiles);
+    const long by_k = d->K / (8 * BK);
+    const long by_ws = (long)(d->workspace_bytes / ((size_t)d->M * d->N * 4));
+    if (want > by_k) want = by_k;
+    if (want > by_ws) want = by_ws;
+    if (want > 64) want = 64;
+    if (want >= 2) splits = (int)want;
+  }
+  k.kchunk = splits > 1 ? (int)(ceil_div(ceil_div(d->K, splits), BK) * BK) : (int)(d->K > 0 ? d->K : 1);
+  if (splits > 1) splits = (int)ceil_div(d->K, k.kchunk);
+  k.splits = splits;
+  k.slab = (float*)d->workspace;
+  dim3 grid(tiles, splits), block(256);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(RNNT_K_GEMM, 2.0 * (double)d->M * (double)d->N * (double)d->K, s);
 #define LAUNCH(AK, BKC, V) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, V>), grid, block, 0, s, k)
@@ -272,5 +336,10 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   else { if (vec) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
 #undef LAUNCH
   RNNT_CHECK_LAUNCH();
+  if (splits > 1) {
+    const long blocks = ceil_div((long)d->M * d->N, 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), block, 0, s, k);
+    RNNT_CHECK_LAUNCH();
+  }
   return RNNT_OK;
 }

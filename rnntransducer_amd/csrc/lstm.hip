@@ -425,18 +425,47 @@ __global__ void permute_bias_kernel(const float* __restrict__ bi0, const float* 
   out[d * 4 * H + idx] = d ? bi1[src] + bh1[src] : bi0[src] + bh0[src];
 }
 
-__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X, long M, long N, long ld,
-                                                     float* __restrict__ out) {
-  // block = 64 columns x 4 row-lanes; grid.x over column tiles; fixed-order reduction (deterministic)
+// two-stage deterministic column sum.  stage 1: grid (ceil(N/64), RC): block (64 columns x 4 row lanes) sums its
+// row chunk into part[rc][n]; stage 2: out[n] = sum_rc part[rc][n] in fixed order.
+constexpr int COLSUM_RC_MAX = 128;
+inline int colsum_chunks(long M, long N) {
+  long want = ceil_div(2048, ceil_div(N, 64));  // ~2048 blocks in flight
+  const long by_m = ceil_div(M, 64);
+  if (want > by_m) want = by_m;
+  if (want > COLSUM_RC_MAX) want = COLSUM_RC_MAX;
+  return (int)(want < 1 ? 1 : want);
+}
+__global__ void __launch_bounds__(256) colsum_stage1_kernel(const float* __restrict__ X, long M, long N, long ld,
+                                                            long rows_per_chunk, float* __restrict__ part) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
   const long n = (long)blockIdx.x * 64 + c;
+  const long m0 = (long)blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
   float s = 0.f;
   if (n < N)
-    for (long m = r; m < M; m += 4) s += X[m * ld + n];
+    for (long m = m0 + r; m < m1; m += 4) s += X[m * ld + n];
   red[r][c] = s;
   __syncthreads();
-  if (r == 0 && n < N) out[n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  if (r == 0 && n < N) part[(long)blockIdx.y * N + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+__global__ void __launch_bounds__(256) colsum_stage2_kernel(const float* __restrict__ part, long N, int rc,
+                                                            float* __restrict__ out) {
+  const long n = (long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < rc; ++k) s += part[(long)k * N + n];
+  out[n] = s;
+}
+int launch_colsum(const float* X, long M, long N, long ld, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int rc = colsum_chunks(M, N);
+  RNNT_CHECK_ARG(ws && ws_bytes >= (size_t)rc * N * 4, "colsum: workspace too small (%zu < %zu)", ws_bytes, (size_t)rc * N * 4);
+  ProfScope prof(RNNT_K_MISC, 4.0 * (double)M * (double)N, s);
+  const long rows = ceil_div(M, rc);
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)ceil_div(N, 64), rc), dim3(256), 0, s, X, M, N, ld, rows, (float*)ws);
+  RNNT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, (const float*)ws, N, rc, out);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
 }
 
 __global__ void embedding_fwd_kernel(const float* __restrict__ W, const long* __restrict__ idx, long M, int H, int V,
@@ -471,6 +500,8 @@ struct LstmWs {
   float* wp;   // (D*4H, I) permuted input weights; reused as dW_ih' in backward
   float* bp;   // (D*4H)
   float* dwhh; // (D*4H, H) scratch for dW_hh'
+  void* scratch;  // split-K slabs of the weight-gradient GEMMs / column-sum partials
+  size_t scratch_bytes;
   size_t total;
 };
 
@@ -515,8 +546,17 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
   w.wp = reinterpret_cast<float*>(take((size_t)D * 4 * H * I * 4));
   w.bp = reinterpret_cast<float*>(take((size_t)D * 4 * H * 4));
   w.dwhh = reinterpret_cast<float*>(take((size_t)D * 4 * H * H * 4));
+  {
+    const int64_t M = (int64_t)T * B, N4 = (int64_t)D * 4 * H;
+    size_t sc = rnnt_hip_gemm_workspace_bytes(N4, I, M);
+    const size_t s2 = rnnt_hip_gemm_workspace_bytes(4 * H, H, M > B ? M - B : 1);
+    const size_t s3 = rnnt_hip_colsum_workspace_bytes(M, N4);
+    if (s2 > sc) sc = s2;
+    if (s3 > sc) sc = s3;
+    w.scratch_bytes = sc;
+    w.scratch = take(sc);
+  }
   w.total = off;
-  (void)T; (void)B;
   return w;
 }
 
@@ -695,6 +735,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     g.A = d->gates; g.a_mc = 1; g.a_sk = N4; g.a_div = 1;
     g.B = d->x; g.b_sn = 1; g.b_sk = I;
     g.C = w.wp; g.c_div = 1; g.c_so = I; g.c_si = 0;
+    g.workspace = w.scratch; g.workspace_bytes = w.scratch_bytes;
     if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
     const long per = (long)4 * H * I;
     hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per,
@@ -710,6 +751,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     g.A = d->gates + shift_g + (int64_t)dir * 4 * H; g.a_mc = 1; g.a_sk = N4; g.a_div = 1;
     g.B = d->y + shift_y + (int64_t)dir * H; g.b_sn = 1; g.b_sk = (int64_t)D * H;
     g.C = w.dwhh + (int64_t)dir * 4 * H * H; g.c_div = 1; g.c_so = H; g.c_si = 0;
+    g.workspace = w.scratch; g.workspace_bytes = w.scratch_bytes;
     if (g.K > 0) {
       if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
     } else {
@@ -724,8 +766,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   }
   // 5. bias gradient = column sums of dG, un-permuted
   {
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N4, 64)), dim3(256), 0, s, d->gates, (long)M, (long)N4, (long)N4, w.bp);
-    RNNT_CHECK_LAUNCH();
+    if ((rc = launch_colsum(d->gates, (long)M, (long)N4, (long)N4, w.bp, w.scratch, w.scratch_bytes, s))) return rc;
     hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, w.bp, H, 1, (long)4 * H,
                        bd->db[0], D > 1 ? bd->db[1] : bd->db[0]);
     RNNT_CHECK_LAUNCH();
@@ -746,11 +787,15 @@ extern "C" int rnnt_hip_lstm_check(const void* workspace, void* stream) {
   return RNNT_OK;
 }
 
-extern "C" int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* stream) {
+extern "C" size_t rnnt_hip_colsum_workspace_bytes(int64_t M, int64_t N) {
+  if (M < 0 || N < 1) return 0;
+  return (size_t)colsum_chunks((long)M, (long)N) * (size_t)N * 4;
+}
+
+extern "C" int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   RNNT_CHECK_ARG(X && out && M >= 0 && N >= 1 && ld >= N, "colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, X, (long)M, (long)N, (long)ld, out);
-  RNNT_CHECK_LAUNCH();
-  return RNNT_OK;
+  return launch_colsum(X, (long)M, (long)N, (long)ld, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int rnnt_hip_embedding_fwd(const float* W, const int64_t* idx, int64_t M, int32_t H, int32_t V, float* out,

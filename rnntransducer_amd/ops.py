@@ -44,10 +44,17 @@ def _addr(t: Optional[torch.Tensor], elem_off: int = 0) -> Optional[int]:
 # --------------------------------------------------------------------------------------------------
 def gemm(M: int, N: int, K: int, A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, *, a_off=0, a_div=BIG, a_so=0,
          a_si=None, a_sk=1, a_mc=False, a_rowidx=None, b_off=0, b_sn=None, b_sk=1, c_off=0, c_div=BIG, c_so=0, c_si=None,
-         bias=None, aux=None, flags=0) -> None:
-    """C(m,n) = sum_k A(m,k) B(k,n) (+bias) — see include/rnnt_hip.h for the operand maps."""
+         bias=None, aux=None, flags=0, split_k=False) -> None:
+    """C(m,n) = sum_k A(m,k) B(k,n) (+bias) — see include/rnnt_hip.h for the operand maps.
+    split_k=True hands the kernel a slab workspace so small-output / deep-K products (weight gradients) fill the chip."""
     _need_gpu(A, B, Cout)
     d = GemmDesc()
+    ws = None
+    if split_k:
+        nws = _lib.lib().rnnt_hip_gemm_workspace_bytes(M, N, K)
+        if nws:
+            ws = torch.empty(nws, device=Cout.device, dtype=torch.uint8)
+            d.workspace, d.workspace_bytes = _addr(ws), nws
     d.M, d.N, d.K = M, N, K
     d.A = _addr(A, a_off)
     d.a_div, d.a_so, d.a_si, d.a_sk = a_div, a_so, (K if a_si is None else a_si), a_sk
@@ -65,7 +72,10 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, B: torch.Tensor, Cout: torch.T
 
 def colsum(X: torch.Tensor, M: int, N: int, ld: Optional[int] = None) -> torch.Tensor:
     out = torch.empty(N, device=X.device, dtype=torch.float32)
-    check(_lib.lib().rnnt_hip_colsum_f32(_addr(X), M, N, N if ld is None else ld, _addr(out), _stream()), "colsum")
+    nws = _lib.lib().rnnt_hip_colsum_workspace_bytes(M, N)
+    ws = torch.empty(max(nws, 16), device=X.device, dtype=torch.uint8)
+    check(_lib.lib().rnnt_hip_colsum_f32(_addr(X), M, N, N if ld is None else ld, _addr(out), _addr(ws), nws, _stream()),
+          "colsum")
     return out
 
 
@@ -99,7 +109,7 @@ class LinearFn(torch.autograd.Function):
             gemm(M, K, N, dy, W, dx, b_sn=1, b_sk=K)          # dx = dy . W
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(W)
-            gemm(N, K, M, dy, x, dW, a_mc=True, a_sk=N, b_sn=1, b_sk=K)  # dW = dy^T . x
+            gemm(N, K, M, dy, x, dW, a_mc=True, a_sk=N, b_sn=1, b_sk=K, split_k=True)  # dW = dy^T . x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N)
         return dx, dW, db
@@ -269,9 +279,10 @@ def _joint_backward(enc, dec, W, dA, dC, needs):
         gemm(U1 * B, Od, V, dC, W, d_dec, b_off=Oe, b_sn=1, b_sk=O, aux=dec, flags=GEMM_MUL_DGELU)
     if needs[2]:
         dW = torch.empty_like(W)
-        gemm(V, Oe, T * B, dA, enc, dW, a_mc=True, a_sk=V, b_sn=1, b_sk=Oe, c_div=1, c_so=O, c_si=0, flags=GEMM_GELU_B)
+        gemm(V, Oe, T * B, dA, enc, dW, a_mc=True, a_sk=V, b_sn=1, b_sk=Oe, c_div=1, c_so=O, c_si=0, flags=GEMM_GELU_B,
+             split_k=True)
         gemm(V, Od, U1 * B, dC, dec, dW, a_mc=True, a_sk=V, b_sn=1, b_sk=Od, c_off=Oe, c_div=1, c_so=O, c_si=0,
-             flags=GEMM_GELU_B)
+             flags=GEMM_GELU_B, split_k=True)
     if needs[3]:
         db = colsum(dA, T * B, V)
     return d_enc, d_dec, dW, db

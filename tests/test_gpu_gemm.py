@@ -89,3 +89,30 @@ def test_gemm_rejects_bad_arguments():
     a = torch.zeros(4, 4, device="cuda")
     with pytest.raises(ValueError):
         gemm(4, 4, 4, a, a, a, b_sn=2, b_sk=2)
+
+
+@pytest.mark.parametrize("M,N,K", [(72, 512, 8000), (256, 96, 4100), (2048, 512, 3000), (130, 70, 129)])
+def test_gemm_split_k_is_exact_sum_and_deterministic(M, N, K):
+    """Weight-gradient shape (small output, deep K): split-K slabs + fixed-order reduce; twice -> bitwise equal."""
+    from rnntransducer_amd._lib import GEMM_ACCUM
+    from rnntransducer_amd.ops import gemm
+    g = torch.Generator().manual_seed(K)
+    A, W = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    ref = A.double().T @ W.double()
+    scale = (A.abs().double().T @ W.abs().double()).max().item()
+    outs = []
+    for _ in range(2):
+        out = torch.ones(M, N, device="cuda")
+        gemm(M, N, K, A.cuda(), W.cuda(), out, a_mc=True, a_sk=M, b_sn=1, b_sk=N, flags=GEMM_ACCUM, split_k=True)
+        outs.append(out)
+    _ref_check(outs[0], ref + 1.0, scale)
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N", [(1, 1), (1000, 72), (32000, 4096), (513, 130)])
+def test_colsum(M, N):
+    from rnntransducer_amd.ops import colsum
+    x = torch.randn(M, N, generator=torch.Generator().manual_seed(M + N))
+    out = colsum(x.cuda(), M, N)
+    ref = x.double().sum(0)
+    assert (out.double().cpu() - ref).abs().max().item() < 1e-5 * max(1.0, x.abs().double().sum(0).max().item())
