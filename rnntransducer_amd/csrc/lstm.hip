@@ -27,6 +27,8 @@
 // with sc1 loads.  No dispatch-order or XCD-placement assumption; all spins are bounded (status word).
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace rnnt {
 namespace {
 
@@ -51,6 +53,7 @@ struct LstmK {
   unsigned* flags; // [D][NC]
   unsigned* status;
   const float* dy; // bwd: (T,B,D,H)
+  int G, Bg, Kp;   // v2: batch groups per direction, rows per group, K padded to a multiple of 64
 };
 
 __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {
@@ -390,6 +393,294 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(const LstmK p) {
   }
 }
 
+
+// ================================================================================================
+// v2 recurrence: D*G sync groups (direction x batch slice) of NC workgroups; a workgroup owns HS hidden units.
+// Measured (tools/sync_probe.hip, profiles/r01_sync_probe.txt): one flag+gather round costs 1.8-2.7 us in a
+// 32-member group with a 16 KB payload vs 6.5-9.4 us in a 128..256-member group with 64 KB -- the cost scales with
+// members and bytes, not with XCD placement.  So the batch is cut into G slices of Bg <= 16 rows; each group's
+// exchange vector is Bg x H (fwd) / Bg x 4H (bwd) and only NC = H/HS workgroups wait on each other.
+// Matrix cores: v_mfma_f32_4x4x1_16B_f32 -- 16 independent 4x4 outer products per instruction.  Blocks are
+// (k-slice, row-quad): fwd rows = the 4 gates of one unit, bwd rows = 4 units; columns = 4 batch rows.  No lane is
+// wasted on an 8-row batch slice, and a lane ends up holding exactly the values one cell update needs.
+// ================================================================================================
+// acc[bq] += sum_{s < Ls} A(ks, s) (x) B(row, ks, s) over this wave's K range.  A comes from LDS (WA_w[s/4][lane] f32x4),
+// B is gathered from the group's exchange rows (global, sc1) in 4 KB blocks through a wave-private LDS stage so that
+// one 16-B ds_read broadcasts a batch row's values to the 16 lanes that need them.
+template <int KS, int BQ>
+__device__ __forceinline__ void gather_mma(__amdgpu_buffer_rsrc_t src, int row_stride_f, int kbase, int Ls,
+                                           const f32x4* __restrict__ WA_w, float* __restrict__ hs, int lane, int myks,
+                                           f32x4 (&acc)[BQ]) {
+  constexpr int NB = 4 * BQ;             // batch rows of the group (padded)
+  constexpr int SB = 256 / (NB * KS);    // 4-step columns per staged block (256 float4 = 4 KB)
+  constexpr int LDB = 4 * SB + (SB > 1 ? 4 : 0);
+  const int ns4 = Ls >> 2;
+  const int nblk = (ns4 + SB - 1) / SB;
+  for (int blk0 = 0; blk0 < nblk; blk0 += 4) {
+    i32x4 r[4][4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = lane + 64 * q;
+        const int s4l = f % SB, ks = (f / SB) % KS, row = f / (SB * KS);
+        const int s4 = (blk0 + bb) * SB + s4l;
+        const bool ok = (blk0 + bb) < nblk && s4 < ns4;
+        const int off = ok ? (row * row_stride_f + kbase + ks * Ls + 4 * s4) * 4 : 0x7ffffff0;  // out of range reads 0
+        r[bb][q] = __builtin_amdgcn_raw_buffer_load_b128(src, off, 0, AUX_SC1);
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const int blk = blk0 + bb;
+      if (blk < nblk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = lane + 64 * q;
+          const int s4l = f % SB, ks = (f / SB) % KS, row = f / (SB * KS);
+          *reinterpret_cast<i32x4*>(&hs[(row * KS + ks) * LDB + 4 * s4l]) = r[bb][q];
+        }
+        const int nsl = min(SB, ns4 - blk * SB);
+        for (int s4l = 0; s4l < nsl; ++s4l) {
+          const f32x4 a = WA_w[(blk * SB + s4l) * 64 + lane];
+#pragma unroll
+          for (int bq = 0; bq < BQ; ++bq) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&hs[((4 * bq + (lane & 3)) * KS + myks) * LDB + 4 * s4l]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[bq] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], b[e], acc[bq], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int KS, int BQ>
+__host__ __device__ constexpr int stage_floats() {
+  return 1024 + 4 * BQ * KS * 4;  // 4 KB block + per-(row, slice) padding
+}
+
+// dynamic LDS: WA[4][Ls/4][64] f32x4 | hs[4][stage_floats] | part[4][BQ][64] f32x4 | abort
+template <int HS, int BQ>
+__global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
+  constexpr int KS = 16 / HS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  const int Kw = Kp / 4, Ls = Kw / KS, ns4 = Ls / 4;
+  f32x4* WA = reinterpret_cast<f32x4*>(smem);
+  float* hs_all = reinterpret_cast<float*>(WA + 4 * ns4 * 64);
+  f32x4* part = reinterpret_cast<f32x4*>(hs_all + 4 * stage_floats<KS, BQ>());
+  int* abort_lds = reinterpret_cast<int*>(part + 4 * BQ * 64);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NG = D * p.G;
+  const int gid = blockIdx.x % NG, wg = blockIdx.x / NG;  // consecutive ids -> different groups (XCD round-robin keeps a group on one XCD when NG == 8; speed only)
+  const int d = gid / p.G, g = gid % p.G;
+  const int b0 = g * p.Bg, j0 = wg * HS;
+
+  {  // weights: lane = 4*blk + i, blk = ks*HS + rq  <->  W_hh[(gate i)*H + j0 + rq][k], k = w*Kw + ks*Ls + 4*s4 + e
+    const float* W = p.w_hh[d];
+    for (int idx = tid; idx < 4 * ns4 * 64; idx += 256) {
+      const int ln = idx & 63, s4 = (idx >> 6) % ns4, w = (idx >> 6) / ns4;
+      const int i = ln & 3, blk = ln >> 2, rq = blk % HS, ks = blk / HS;
+      const int k = w * Kw + ks * Ls + 4 * s4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const float* row = W + (long)(i * H + j0 + rq) * H;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < H) v[e] = row[k + e];
+      WA[idx] = v;
+    }
+    if (tid == 0) *abort_lds = 0;
+  }
+  constexpr int NBR = 4 * BQ;
+  const long hx_floats = (long)NBR * Kp;
+  __amdgpu_buffer_rsrc_t hx_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    hx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(p.hx + ((long)par * NG + gid) * hx_floats, 0, (int)(hx_floats * 4), RSRC_FLAGS);
+  unsigned* flags = p.flags + gid * p.NC;
+
+  // cell owners: tid = obq*(4*HS) + 4*unit + j : the lane that ends up with the 4 gate sums of (unit, batch row 4*obq+j)
+  const bool owner = tid < BQ * 4 * HS;
+  const int ol = tid % (4 * HS), obq = tid / (4 * HS);
+  const int ounit = ol >> 2, brow = 4 * obq + (ol & 3);
+  const int ob = b0 + brow, oj = j0 + ounit;
+  const bool valid = owner && brow < p.Bg && ob < B;
+  const int olen = valid ? p.lens[ob] : 0;
+  float c_state = 0.f;
+  const int myks = (lane >> 2) / HS;
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = (d == 0) ? s : T - 1 - s;
+    f32x4 xp = {0.f, 0.f, 0.f, 0.f};
+    const long grow = ((long)t * B + ob) * D + d;
+    if (valid) xp = *reinterpret_cast<const f32x4*>(p.gates + grow * 4 * H + 4 * oj);
+
+    f32x4 acc[BQ];
+#pragma unroll
+    for (int bq = 0; bq < BQ; ++bq) acc[bq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return;
+      gather_mma<KS, BQ>(hx_rsrc[(s - 1) & 1], Kp, wave * Kw, Ls, WA + wave * ns4 * 64,
+                         hs_all + wave * stage_floats<KS, BQ>(), lane, myks, acc);
+    }
+#pragma unroll
+    for (int bq = 0; bq < BQ; ++bq) part[(wave * BQ + bq) * 64 + lane] = acc[bq];
+    __syncthreads();
+    if (owner) {
+      f32x4 g4 = xp;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) g4 += part[(w * BQ + obq) * 64 + ks * 4 * HS + ol];
+      const bool active = valid && t < olen;
+      float hval = 0.f;
+      f32x4 gact = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+        c_state = fg * c_state + ig * gg;
+        hval = og * tanhf(c_state);
+        gact = (f32x4){ig, fg, gg, og};
+      } else {
+        c_state = 0.f;
+      }
+      // 4 consecutive units of one batch row sit in lanes l, l+4, l+8, l+12: collect them in the first
+      f32x4 h4, c4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h4[e] = __shfl(hval, lane + 4 * e);
+        c4[e] = __shfl(c_state, lane + 4 * e);
+      }
+      const bool quad_lead = (ounit & 3) == 0;
+      if (quad_lead)  // exchange slice first: it is what the other workgroups of the group wait for
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h4), hx_rsrc[s & 1], (brow * Kp + oj) * 4, 0, AUX_SC1);
+      if (valid) {
+        *reinterpret_cast<f32x4*>(p.gates + grow * 4 * H + 4 * oj) = gact;
+        if (quad_lead) {
+          *reinterpret_cast<f32x4*>(p.cst + ((((long)d * T + t) * (H / 4) + (oj >> 2)) * B + ob) * 4) = c4;
+          const long yo = grow * H + oj;
+          *reinterpret_cast<f32x4*>(p.y + yo) = h4;
+          if (p.ydrop) {
+            f32x4 hd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              hd[e] = (hash_u32(p.seed, (unsigned long long)(yo + e)) >= p.drop_thresh) ? h4[e] * p.keep_scale : 0.f;
+            *reinterpret_cast<f32x4*>(p.ydrop + yo) = hd;
+          }
+        }
+      }
+    }
+    publish_flag(flags + wg, (unsigned)(s + 1));
+  }
+}
+
+// dynamic LDS: WA[4][Ls/4][64] f32x4 | hs[4][stage_floats] | part[4][BQ][64] f32x4 | abort
+template <int HS, int BQ>
+__global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
+  constexpr int UQ = HS / 4, KS = 16 / UQ;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  const int Kw = Kp, Ls = Kw / KS, ns4 = Ls / 4;  // contraction index k = 4*j' + gate over 4*Kp, a quarter per wave
+  f32x4* WA = reinterpret_cast<f32x4*>(smem);
+  float* hs_all = reinterpret_cast<float*>(WA + 4 * ns4 * 64);
+  float* part = hs_all + 4 * stage_floats<KS, BQ>();
+  int* abort_lds = reinterpret_cast<int*>(part + 4 * BQ * 64 * 4);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NG = D * p.G;
+  const int gid = blockIdx.x % NG, wg = blockIdx.x / NG;
+  const int d = gid / p.G, g = gid % p.G;
+  const int b0 = g * p.Bg, j0 = wg * HS;
+
+  {  // weights: lane = 4*blk + i, blk = ks*UQ + uq  <->  W_hh[(gate k&3)*H + (k>>2)][j0 + 4*uq + i]
+    const float* W = p.w_hh[d];
+    for (int idx = tid; idx < 4 * ns4 * 64; idx += 256) {
+      const int ln = idx & 63, s4 = (idx >> 6) % ns4, w = (idx >> 6) / ns4;
+      const int i = ln & 3, blk = ln >> 2, uq = blk % UQ, ks = blk / UQ;
+      const int k = w * Kw + ks * Ls + 4 * s4;  // multiple of 4: e is the gate, k>>2 the unit j'
+      const int jp = k >> 2, col = j0 + 4 * uq + i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (jp < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = W[(long)(e * H + jp) * H + col];
+      }
+      WA[idx] = v;
+    }
+    if (tid == 0) *abort_lds = 0;
+  }
+  constexpr int NBR = 4 * BQ;
+  const long gx_floats = (long)NBR * 4 * Kp;
+  __amdgpu_buffer_rsrc_t gx_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    gx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(p.hx + ((long)par * NG + gid) * gx_floats, 0, (int)(gx_floats * 4), RSRC_FLAGS);
+  unsigned* flags = p.flags + gid * p.NC;
+
+  // cell owners: tid = ((obq*UQ + uq)*4 + i)*4 + j -> unit j0 + 4*uq + i, batch row 4*obq + j
+  const bool owner = tid < BQ * HS * 4;
+  const int ojb = tid & 3, oi = (tid >> 2) & 3, ouq = (tid >> 4) % UQ, obq = (tid >> 4) / UQ;
+  const int brow = 4 * obq + ojb, ob = b0 + brow, oj = j0 + 4 * ouq + oi;
+  const bool valid = owner && brow < p.Bg && ob < B;
+  const int olen = valid ? p.lens[ob] : 0;
+  float dc_carry = 0.f;
+  const int myks = (lane >> 2) / UQ;
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = (d == 0) ? T - 1 - s : s;
+    const int tprev = (d == 0) ? t - 1 : t + 1;
+    f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+    float c_t = 0.f, c_p = 0.f, dyv = 0.f;
+    const long grow = ((long)t * B + ob) * D + d;
+    const bool active = valid && t < olen;
+    if (active) {
+      gt = *reinterpret_cast<const f32x4*>(p.gates + grow * 4 * H + 4 * oj);
+      c_t = p.cst[((((long)d * T + t) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)];
+      if (tprev >= 0 && tprev < T) c_p = p.cst[((((long)d * T + tprev) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)];
+      const long yo = grow * H + oj;
+      dyv = p.dy[yo];
+      if (p.ydrop) dyv = (hash_u32(p.seed, (unsigned long long)yo) >= p.drop_thresh) ? dyv * p.keep_scale : 0.f;
+    }
+
+    f32x4 acc[BQ];
+#pragma unroll
+    for (int bq = 0; bq < BQ; ++bq) acc[bq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return;
+      gather_mma<KS, BQ>(gx_rsrc[(s - 1) & 1], 4 * Kp, wave * Kw, Ls, WA + wave * ns4 * 64,
+                         hs_all + wave * stage_floats<KS, BQ>(), lane, myks, acc);
+    }
+#pragma unroll
+    for (int bq = 0; bq < BQ; ++bq) *reinterpret_cast<f32x4*>(&part[((wave * BQ + bq) * 64 + lane) * 4]) = acc[bq];
+    __syncthreads();
+    if (owner) {
+      float dh = dyv;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dh += part[((w * BQ + obq) * 64 + 4 * (ks * UQ + ouq) + ojb) * 4 + oi];
+      f32x4 dg4 = {0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
+        const float tc = tanhf(c_t);
+        const float dc = dh * og * (1.f - tc * tc) + dc_carry;
+        dg4[0] = dc * gg * ig * (1.f - ig);
+        dg4[1] = dc * c_p * fg * (1.f - fg);
+        dg4[2] = dc * ig * (1.f - gg * gg);
+        dg4[3] = dh * tc * og * (1.f - og);
+        dc_carry = dc * fg;
+      } else {
+        dc_carry = 0.f;
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dg4), gx_rsrc[s & 1], (brow * 4 * Kp + 4 * oj) * 4, 0, AUX_SC1);
+      if (valid) *reinterpret_cast<f32x4*>(p.gates + grow * 4 * H + 4 * oj) = dg4;
+    }
+    publish_flag(flags + wg, (unsigned)(s + 1));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
@@ -492,6 +783,13 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ dE, const long* _
   }
 }
 
+int device_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return cus;
+}
+
 struct LstmWs {
   unsigned* flags;  // [16 words: status at word 0] [D*NC step flags], zeroed per launch
   size_t sync_bytes;
@@ -534,14 +832,62 @@ bool make_plan(int B, int H, int D, int cus, Plan* pl) {
   return false;
 }
 
+struct Plan2 {
+  int HS, NC, G, Bg, BQ, Kp;
+  size_t lds_fwd, lds_bwd;
+};
+
+// v2 decomposition: largest hidden slice whose W_hh rows fit LDS (fewest workgroups per sync group), then as many
+// batch slices as the CUs allow.  Returns false when the shape does not fit (caller falls back to v1).
+bool make_plan2(int B, int H, int D, int cus, Plan2* pl) {
+  if (H < 4 || H % 4 != 0 || B < 1 || D < 1 || D > 2) return false;
+  if (getenv("RNNT_LSTM_V1")) return false;
+  const int Kp = (int)align_up((size_t)H, 64);
+  for (int HS = 16; HS >= 4; HS /= 2) {
+    if (H % HS != 0) continue;
+    const int NC = H / HS;
+    const int Gmax = cus / (D * NC);
+    if (Gmax < 1) continue;
+    int G = (int)ceil_div(B, 4);
+    if (G > Gmax) G = Gmax;
+    const int Bg = (int)ceil_div(B, G);
+    if (Bg > 16) continue;
+    G = (int)ceil_div(B, Bg);
+    const int BQ = Bg <= 4 ? 1 : (Bg <= 8 ? 2 : 4);
+    const int KSf = 16 / HS, KSb = 64 / HS;
+    const size_t wa = (size_t)16 * Kp * HS;
+    const size_t part = (size_t)4 * BQ * 64 * 16;
+    const size_t lds_f = wa + (size_t)4 * (1024 + 4 * BQ * KSf * 4) * 4 + part + 16;
+    const size_t lds_b = wa + (size_t)4 * (1024 + 4 * BQ * KSb * 4) * 4 + part + 16;
+    if (lds_f > 160 * 1024 || lds_b > 160 * 1024) continue;
+    pl->HS = HS; pl->NC = NC; pl->G = G; pl->Bg = Bg; pl->BQ = BQ; pl->Kp = Kp;
+    pl->lds_fwd = lds_f; pl->lds_bwd = lds_b;
+    return true;
+  }
+  return false;
+}
+
 LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
   LstmWs w;
   char* p = reinterpret_cast<char*>(ws);
   size_t off = 0;
   auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off += align_up(bytes, 256); return q; };
-  w.sync_bytes = align_up((size_t)(D * pl.NC + 16) * 4, 16);
+  size_t nflags = (size_t)D * pl.NC;
+  size_t hxb = (size_t)2 * D * H * pl.Bp * 4 * 4;  // v1, sized for the backward exchange (B x 4H), fwd uses a quarter
+  {
+    Plan2 p2;
+    int cus = device_cus();
+    if (cus <= 0) cus = 256;
+    if (make_plan2(B, H, D, cus, &p2)) {
+      const size_t nf2 = (size_t)D * p2.G * p2.NC;
+      const size_t hx2 = (size_t)2 * D * p2.G * 4 * p2.BQ * 4 * p2.Kp * 4;
+      if (nf2 > nflags) nflags = nf2;
+      if (hx2 > hxb) hxb = hx2;
+    }
+  }
+  w.sync_bytes = align_up((nflags + 16) * 4, 16);
   w.flags = reinterpret_cast<unsigned*>(take(w.sync_bytes));
-  w.hx_bytes = (size_t)2 * D * H * pl.Bp * 4 * 4;  // sized for the backward exchange (B x 4H), fwd uses a quarter
+  w.hx_bytes = hxb;
   w.hx = reinterpret_cast<float*>(take(w.hx_bytes));
   w.wp = reinterpret_cast<float*>(take((size_t)D * 4 * H * I * 4));
   w.bp = reinterpret_cast<float*>(take((size_t)D * 4 * H * 4));
@@ -558,13 +904,6 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
   }
   w.total = off;
   return w;
-}
-
-int device_cus() {
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  return cus;
 }
 
 template <typename K>
@@ -588,6 +927,44 @@ int launch_persistent(K kernel, const LstmK& k, const Plan& pl, size_t lds, hipS
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }
+
+template <typename K>
+int launch_persistent2(K kernel, const LstmK& k, const Plan2& pl, size_t lds, hipStream_t s, const char* what) {
+  if (lds > 64 * 1024)
+    RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  RNNT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
+  const int cus = device_cus();
+  const int grid = k.D * pl.G * pl.NC;
+  if (per_cu < 1 || grid > cus) {
+    set_error("%s: %d workgroups cannot be co-resident (%d CUs x %d per CU)", what, grid, cus, per_cu);
+    return RNNT_ERR_UNSUPPORTED;
+  }
+  {
+    const double per_tb = (k.dy ? (8.0 + 2.0 + 1.0) : (8.0 + 1.0 + 1.0)) * k.H * 4.0;
+    ProfScope prof(k.dy ? RNNT_K_LSTM_BWD : RNNT_K_LSTM_FWD, per_tb * k.T * k.B * k.D + 4.0 * 4.0 * k.H * k.H * k.D, s);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, k);
+  }
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+#define DISPATCH_HS_BQ(KERNEL, pl, ...)                                                     \
+  do {                                                                                      \
+    const int key_ = (pl).HS * 10 + (pl).BQ;                                                \
+    switch (key_) {                                                                         \
+      case 41: rc = launch_persistent2(KERNEL<4, 1>, __VA_ARGS__); break;                   \
+      case 42: rc = launch_persistent2(KERNEL<4, 2>, __VA_ARGS__); break;                   \
+      case 44: rc = launch_persistent2(KERNEL<4, 4>, __VA_ARGS__); break;                   \
+      case 81: rc = launch_persistent2(KERNEL<8, 1>, __VA_ARGS__); break;                   \
+      case 82: rc = launch_persistent2(KERNEL<8, 2>, __VA_ARGS__); break;                   \
+      case 84: rc = launch_persistent2(KERNEL<8, 4>, __VA_ARGS__); break;                   \
+      case 161: rc = launch_persistent2(KERNEL<16, 1>, __VA_ARGS__); break;                 \
+      case 162: rc = launch_persistent2(KERNEL<16, 2>, __VA_ARGS__); break;                 \
+      case 164: rc = launch_persistent2(KERNEL<16, 4>, __VA_ARGS__); break;                 \
+      default: set_error("lstm: no v2 kernel for HS=%d BQ=%d", (pl).HS, (pl).BQ); rc = RNNT_ERR_UNSUPPORTED; \
+    }                                                                                       \
+  } while (0)
 
 int check_desc(const rnnt_lstm_desc* d, Plan* pl, LstmWs* w) {
   RNNT_CHECK_ARG(d != nullptr, "lstm: null descriptor");
@@ -688,7 +1065,13 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   LstmK k;
   fill_kernel_args(d, pl, w, &k);
   int rc = RNNT_OK;
-  DISPATCH_MT_NT(lstm_fwd_kernel, pl, k, pl, pl.lds_fwd, s, "lstm_fwd");
+  Plan2 p2;
+  if (make_plan2(d->B, d->H, d->D, device_cus(), &p2)) {
+    k.NC = p2.NC; k.Hs = p2.HS; k.G = p2.G; k.Bg = p2.Bg; k.Kp = p2.Kp;
+    DISPATCH_HS_BQ(lstm_fwd2_kernel, p2, k, p2, p2.lds_fwd, s, "lstm_fwd2");
+  } else {
+    DISPATCH_MT_NT(lstm_fwd_kernel, pl, k, pl, pl.lds_fwd, s, "lstm_fwd");
+  }
   return rc;
 }
 
@@ -711,7 +1094,13 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   fill_kernel_args(d, pl, w, &k);
   k.dy = bd->dy;
   int rc = RNNT_OK;
-  DISPATCH_MT_NT(lstm_bwd_kernel, pl, k, pl, pl.lds_bwd, s, "lstm_bwd");
+  Plan2 p2;
+  if (make_plan2(d->B, d->H, d->D, device_cus(), &p2)) {
+    k.NC = p2.NC; k.Hs = p2.HS; k.G = p2.G; k.Bg = p2.Bg; k.Kp = p2.Kp;
+    DISPATCH_HS_BQ(lstm_bwd2_kernel, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
+  } else {
+    DISPATCH_MT_NT(lstm_bwd_kernel, pl, k, pl, pl.lds_bwd, s, "lstm_bwd");
+  }
   if (rc) return rc;
 
   const int64_t M = (int64_t)T * B, N4 = (int64_t)D * 4 * H;

@@ -109,3 +109,11 @@ def test_lstm_rejects_unsupported():
         hip(torch.zeros(2, 2, 4, device="cuda"), torch.tensor([2, 2], device="cuda"))  # int64 lengths
     with pytest.raises(RnntHipError):
         hip(torch.zeros(2, 2, 4), torch.tensor([2, 2], dtype=torch.int32))            # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("B,T,I,H,L,bi", [(3, 7, 5, 8, 1, True), (33, 6, 16, 20, 2, True), (2, 25, 16, 512, 1, True)])
+def test_lstm_v1_fallback_kernels_still_match(monkeypatch, B, T, I, H, L, bi):
+    """The 128-workgroup-per-direction kernels (used when a shape does not fit the grouped v2 decomposition, e.g.
+    H = 1024 with B > 16) stay covered: force them with RNNT_LSTM_V1=1."""
+    monkeypatch.setenv("RNNT_LSTM_V1", "1")
+    test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
