@@ -53,6 +53,7 @@ SYMBOLS = {
     "rnnt_hip_lstm_fwd": (C.c_int, [C.POINTER(LstmDesc), C.c_void_p]),
     "rnnt_hip_lstm_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), C.c_void_p]),
     "rnnt_hip_lstm_check": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rnnt_hip_lstm_debug_read": (C.c_int, [C.c_void_p, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_void_p, c_i32, C.c_void_p]),
     "rnnt_hip_joint_loss_workspace_bytes": (C.c_size_t, [c_i32] * 4),
     "rnnt_hip_joint_loss_fwd_bwd": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_float,

@@ -60,6 +60,14 @@ __device__ __forceinline__ float dgelu_tanh(float x) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh through one exp: |abs err| ~ 1e-7, saturates to +-1 (exp -> inf / 0); much shorter than ocml tanhf on the
+// per-timestep critical path of the recurrences
+__device__ __forceinline__ float tanh_e(float x) { return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f); }
+// hardware-transcendental forms for the per-timestep critical path of the persistent recurrences, where ONE wave
+// issues one VALU instruction per 4 cycles and ocml expf + IEEE division cost ~100 instructions per cell:
+// v_exp_f32 / v_rcp_f32 are 1 ulp each -> |abs err| ~ 2e-7 on values in [-1, 1]; saturate correctly at +-inf.
+__device__ __forceinline__ float sigmoid_hw(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_hw(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -29,6 +29,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace rnnt {
 namespace {
 
@@ -54,14 +56,30 @@ struct LstmK {
   unsigned* status;
   const float* dy; // bwd: (T,B,D,H)
   int G, Bg, Kp;   // v2: batch groups per direction, rows per group, K padded to a multiple of 64
+  unsigned long long* dbg;  // diagnostic builds only (RNNT_LSTM_DBG): per-workgroup phase cycle sums, else nullptr
+  unsigned* xcc;   // v2: [D*G][NC] XCC id + 1 of every member, published once at kernel start (zeroed per launch)
+  int allow_local; // v2: permit the L2-local exchange when a group is verified to sit on one XCD
 };
 
+#define DBG_STAMP(i) do { if (p.dbg && tid == 0) { const unsigned long long now_ = clock64(); dsum[i] += now_ - dlast; dlast = now_; } } while (0)
+
+// counter-based dropout mask: murmur3-style 32-bit finaliser of (seed, element index) -- a dozen 32-bit ops, the
+// forward and backward kernels regenerate the same mask from the same (seed, index)
 __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (unsigned)(z >> 32);
+  unsigned h = (unsigned)idx ^ (unsigned)seed;
+  h ^= ((unsigned)(idx >> 32) + (unsigned)(seed >> 32)) * 0x27d4eb2fu;
+  h *= 0x9E3779B1u;
+  h ^= h >> 15;
+  h *= 0x85EBCA77u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 16;
+  return h;
+}
+// value of lane (l + n) within the same 16-lane row (n = 4, 8, 12): one DPP move, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ float row_shl(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
 }
 
 // Wave 0 polls this direction's step flags until all are >= need; everyone then joins a barrier.
@@ -404,6 +422,49 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(const LstmK p) {
 // (k-slice, row-quad): fwd rows = the 4 gates of one unit, bwd rows = 4 units; columns = 4 batch rows.  No lane is
 // wasted on an 8-row batch slice, and a lane ends up holding exactly the values one cell update needs.
 // ================================================================================================
+
+// ---- XCD-local exchange (speed only; correctness never depends on placement) -------------------------------------
+// All CUs of one XCD share one L2.  When every member of a sync group is VERIFIED at run time (HW_REG_XCC_ID, exchanged
+// once through the placement-independent sc1 protocol) to sit on the same XCD, the group switches its per-step
+// exchange to plain stores (the line stays in that L2) + sc1 loads (bypass L1, hit L2): measured 1.96 vs 2.74 us per
+// round in tools/sync_probe.hip.  A group that spans XCDs keeps the write-through protocol.  The decision is uniform
+// across a group because every member evaluates the same published table.
+__device__ __forceinline__ bool group_is_xcd_local(unsigned* xtab, int nmem, int me, unsigned* status, int* lds_flag) {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc = (xcc & 0xfu) + 1u;
+  if (threadIdx.x == 0) __hip_atomic_store(xtab + me, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!wait_flags(xtab, nmem, 1u, status, lds_flag)) return false;
+  if (threadIdx.x < 64) {
+    bool same = true;
+    for (int i = threadIdx.x; i < nmem; i += 64)
+      same = same && (__hip_atomic_load(xtab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc);
+    same = __all(same);
+    if (threadIdx.x == 0) *lds_flag = same ? 2 : 0;
+  }
+  __syncthreads();
+  const bool local = *lds_flag == 2;
+  __syncthreads();
+  if (threadIdx.x == 0) *lds_flag = 0;
+  __syncthreads();
+  return local;
+}
+
+template <bool LOCAL>
+__device__ __forceinline__ void exchange_store(i32x4 v, __amdgpu_buffer_rsrc_t r, int off) {
+  if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, AUX_SC1);
+}
+template <bool LOCAL>
+__device__ __forceinline__ void publish_flag2(unsigned* flag, unsigned value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if constexpr (LOCAL) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // acc[bq] += sum_{s < Ls} A(ks, s) (x) B(row, ks, s) over this wave's K range.  A comes from LDS (WA_w[s/4][lane] f32x4),
 // B is gathered from the group's exchange rows (global, sc1) in 4 KB blocks through a wave-private LDS stage so that
 // one 16-B ds_read broadcasts a batch row's values to the 16 lanes that need them.
@@ -416,6 +477,9 @@ __device__ __forceinline__ void gather_mma(__amdgpu_buffer_rsrc_t src, int row_s
   constexpr int LDB = 4 * SB + (SB > 1 ? 4 : 0);
   const int ns4 = Ls >> 2;
   const int nblk = (ns4 + SB - 1) / SB;
+  f32x4 acc2[2][BQ];
+#pragma unroll
+  for (int bq = 0; bq < BQ; ++bq) acc2[0][bq] = acc2[1][bq] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int blk0 = 0; blk0 < nblk; blk0 += 4) {
     i32x4 r[4][4];
 #pragma unroll
@@ -441,18 +505,55 @@ __device__ __forceinline__ void gather_mma(__amdgpu_buffer_rsrc_t src, int row_s
           *reinterpret_cast<i32x4*>(&hs[(row * KS + ks) * LDB + 4 * s4l]) = r[bb][q];
         }
         const int nsl = min(SB, ns4 - blk * SB);
-        for (int s4l = 0; s4l < nsl; ++s4l) {
-          const f32x4 a = WA_w[(blk * SB + s4l) * 64 + lane];
+        // software pipeline: chunks of U steps, register ping-pong, so the next chunk's LDS reads are in flight
+        // under this chunk's MFMAs; two accumulator sets (even/odd step) keep dependent MFMAs 2*BQ apart
+        constexpr int U = 4;
+        const f32x4* wa = WA_w + (long)blk * SB * 64 + lane;
+        const float* hb = hs + ((lane & 3) * KS + myks) * LDB;
+        auto lds_load = [&](int s0, f32x4(&av)[U], f32x4(&bv)[U][BQ]) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            av[u] = wa[(s0 + u) * 64];
+#pragma unroll
+            for (int bq = 0; bq < BQ; ++bq) bv[u][bq] = *reinterpret_cast<const f32x4*>(&hb[4 * bq * KS * LDB + 4 * (s0 + u)]);
+          }
+        };
+        auto mma = [&](const f32x4(&av)[U], const f32x4(&bv)[U][BQ]) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int bq = 0; bq < BQ; ++bq)
+                acc2[u & 1][bq] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u][e], bv[u][bq][e], acc2[u & 1][bq], 0, 0, 0);
+        };
+        const int nfull = nsl / U;
+        if (nfull > 0) {
+          f32x4 a0[U], b0[U][BQ], a1[U], b1[U][BQ];
+          lds_load(0, a0, b0);
+          int c = 0;
+          for (; c + 2 <= nfull; c += 2) {
+            lds_load((c + 1) * U, a1, b1);
+            mma(a0, b0);
+            if (c + 2 < nfull) lds_load((c + 2) * U, a0, b0);
+            mma(a1, b1);
+          }
+          if (c < nfull) mma(a0, b0);
+        }
+        for (int s4l = nfull * U; s4l < nsl; ++s4l) {
+          const f32x4 av = wa[s4l * 64];
 #pragma unroll
           for (int bq = 0; bq < BQ; ++bq) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&hs[((4 * bq + (lane & 3)) * KS + myks) * LDB + 4 * s4l]);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&hb[4 * bq * KS * LDB + 4 * s4l]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[bq] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], b[e], acc[bq], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc2[0][bq] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], bv[e], acc2[0][bq], 0, 0, 0);
           }
         }
       }
     }
   }
+#pragma unroll
+  for (int bq = 0; bq < BQ; ++bq) acc[bq] += acc2[0][bq] + acc2[1][bq];
 }
 
 template <int KS, int BQ>
@@ -510,25 +611,41 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
   const int olen = valid ? p.lens[ob] : 0;
   float c_state = 0.f;
   const int myks = (lane >> 2) / HS;
+  // per-step addresses advance by constant strides: keep running offsets instead of 64-bit multiplies in the loop
+  const int t_first = (d == 0) ? 0 : T - 1;
+  const long tdir = (d == 0) ? 1 : -1;
+  long g_off = (((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj;                   // gates
+  long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4;        // cst
+  long y_off = (((long)t_first * B + ob) * D + d) * H + oj;                           // y / y_drop
+  const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
+  const int hx_off = (brow * Kp + oj) * 4;
   __syncthreads();
+  unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
+  const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
 
+  auto run = [&](auto local_tag) -> bool {
+  constexpr bool LOCAL = decltype(local_tag)::value;
   for (int s = 0; s < T; ++s) {
     const int t = (d == 0) ? s : T - 1 - s;
     f32x4 xp = {0.f, 0.f, 0.f, 0.f};
-    const long grow = ((long)t * B + ob) * D + d;
-    if (valid) xp = *reinterpret_cast<const f32x4*>(p.gates + grow * 4 * H + 4 * oj);
+    if (valid) xp = *reinterpret_cast<const f32x4*>(p.gates + g_off);
 
     f32x4 acc[BQ];
 #pragma unroll
     for (int bq = 0; bq < BQ; ++bq) acc[bq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    DBG_STAMP(0);  // prefetch issue
     if (s > 0) {
-      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return;
+      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return false;
+      DBG_STAMP(1);  // flag wait
       gather_mma<KS, BQ>(hx_rsrc[(s - 1) & 1], Kp, wave * Kw, Ls, WA + wave * ns4 * 64,
                          hs_all + wave * stage_floats<KS, BQ>(), lane, myks, acc);
+      DBG_STAMP(2);  // gather + MFMA
     }
 #pragma unroll
     for (int bq = 0; bq < BQ; ++bq) part[(wave * BQ + bq) * 64 + lane] = acc[bq];
     __syncthreads();
+    f32x4 gact = {0.f, 0.f, 0.f, 0.f}, h4 = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
+    bool quad_lead = false;
     if (owner) {
       f32x4 g4 = xp;
 #pragma unroll
@@ -537,43 +654,51 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
         for (int ks = 0; ks < KS; ++ks) g4 += part[(w * BQ + obq) * 64 + ks * 4 * HS + ol];
       const bool active = valid && t < olen;
       float hval = 0.f;
-      f32x4 gact = {0.f, 0.f, 0.f, 0.f};
       if (active) {
-        const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+        const float ig = sigmoid_hw(g4[0]), fg = sigmoid_hw(g4[1]), gg = tanh_hw(g4[2]), og = sigmoid_hw(g4[3]);
         c_state = fg * c_state + ig * gg;
-        hval = og * tanhf(c_state);
+        hval = og * tanh_hw(c_state);
         gact = (f32x4){ig, fg, gg, og};
       } else {
         c_state = 0.f;
       }
       // 4 consecutive units of one batch row sit in lanes l, l+4, l+8, l+12: collect them in the first
-      f32x4 h4, c4;
+      h4 = (f32x4){hval, row_shl<0x104>(hval), row_shl<0x108>(hval), row_shl<0x10C>(hval)};
+      c4 = (f32x4){c_state, row_shl<0x104>(c_state), row_shl<0x108>(c_state), row_shl<0x10C>(c_state)};
+      quad_lead = (ounit & 3) == 0;
+      if (quad_lead)  // ONLY the exchange slice is stored before the flag: it is what the group waits for
+        exchange_store<LOCAL>(__builtin_bit_cast(i32x4, h4), hx_rsrc[s & 1], hx_off);
+    }
+    DBG_STAMP(3);  // LDS reduce + cell math + exchange store issue
+    publish_flag2<LOCAL>(flags + wg, (unsigned)(s + 1));
+    DBG_STAMP(4);  // drain + barrier + flag
+    // stash / layer-output stores AFTER the flag: they overlap the group's next exchange instead of delaying it
+    if (valid) {
+      *reinterpret_cast<f32x4*>(p.gates + g_off) = gact;
+      if (quad_lead) {
+        *reinterpret_cast<f32x4*>(p.cst + c_off) = c4;
+        const long yo = y_off;
+        *reinterpret_cast<f32x4*>(p.y + yo) = h4;
+        if (p.ydrop) {
+          f32x4 hd;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        h4[e] = __shfl(hval, lane + 4 * e);
-        c4[e] = __shfl(c_state, lane + 4 * e);
-      }
-      const bool quad_lead = (ounit & 3) == 0;
-      if (quad_lead)  // exchange slice first: it is what the other workgroups of the group wait for
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h4), hx_rsrc[s & 1], (brow * Kp + oj) * 4, 0, AUX_SC1);
-      if (valid) {
-        *reinterpret_cast<f32x4*>(p.gates + grow * 4 * H + 4 * oj) = gact;
-        if (quad_lead) {
-          *reinterpret_cast<f32x4*>(p.cst + ((((long)d * T + t) * (H / 4) + (oj >> 2)) * B + ob) * 4) = c4;
-          const long yo = grow * H + oj;
-          *reinterpret_cast<f32x4*>(p.y + yo) = h4;
-          if (p.ydrop) {
-            f32x4 hd;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              hd[e] = (hash_u32(p.seed, (unsigned long long)(yo + e)) >= p.drop_thresh) ? h4[e] * p.keep_scale : 0.f;
-            *reinterpret_cast<f32x4*>(p.ydrop + yo) = hd;
-          }
+          for (int e = 0; e < 4; ++e)
+            hd[e] = (hash_u32(p.seed, (unsigned long long)(yo + e)) >= p.drop_thresh) ? h4[e] * p.keep_scale : 0.f;
+          *reinterpret_cast<f32x4*>(p.ydrop + yo) = hd;
         }
       }
     }
-    publish_flag(flags + wg, (unsigned)(s + 1));
+    g_off += g_step;
+    c_off += c_step;
+    y_off += y_step;
+    DBG_STAMP(5);  // stash stores issue
   }
+  return true;
+  };
+  const bool ok = local ? run(std::true_type{}) : run(std::false_type{});
+  if (!ok) return;
+  if (p.dbg && tid == 0)
+    for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
 }
 
 // dynamic LDS: WA[4][Ls/4][64] f32x4 | hs[4][stage_floats] | part[4][BQ][64] f32x4 | abort
@@ -626,20 +751,30 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
   const int olen = valid ? p.lens[ob] : 0;
   float dc_carry = 0.f;
   const int myks = (lane >> 2) / UQ;
+  const int t_first = (d == 0) ? T - 1 : 0;
+  const long tdir = (d == 0) ? -1 : 1;
+  long g_off = (((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj;
+  long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3);
+  long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
+  const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
+  const int gx_off = (brow * 4 * Kp + 4 * oj) * 4;
   __syncthreads();
+  unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
+  const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
 
+  auto run = [&](auto local_tag) -> bool {
+  constexpr bool LOCAL = decltype(local_tag)::value;
   for (int s = 0; s < T; ++s) {
     const int t = (d == 0) ? T - 1 - s : s;
     const int tprev = (d == 0) ? t - 1 : t + 1;
     f32x4 gt = {0.f, 0.f, 0.f, 0.f};
     float c_t = 0.f, c_p = 0.f, dyv = 0.f;
-    const long grow = ((long)t * B + ob) * D + d;
     const bool active = valid && t < olen;
     if (active) {
-      gt = *reinterpret_cast<const f32x4*>(p.gates + grow * 4 * H + 4 * oj);
-      c_t = p.cst[((((long)d * T + t) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)];
-      if (tprev >= 0 && tprev < T) c_p = p.cst[((((long)d * T + tprev) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)];
-      const long yo = grow * H + oj;
+      gt = *reinterpret_cast<const f32x4*>(p.gates + g_off);
+      c_t = p.cst[c_off];
+      if (tprev >= 0 && tprev < T) c_p = p.cst[c_off + c_step];  // the backward walks towards the forward's t_prev
+      const long yo = y_off;
       dyv = p.dy[yo];
       if (p.ydrop) dyv = (hash_u32(p.seed, (unsigned long long)yo) >= p.drop_thresh) ? dyv * p.keep_scale : 0.f;
     }
@@ -647,24 +782,27 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
     f32x4 acc[BQ];
 #pragma unroll
     for (int bq = 0; bq < BQ; ++bq) acc[bq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    DBG_STAMP(0);  // prefetch issue
     if (s > 0) {
-      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return;
+      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return false;
+      DBG_STAMP(1);  // flag wait
       gather_mma<KS, BQ>(gx_rsrc[(s - 1) & 1], 4 * Kp, wave * Kw, Ls, WA + wave * ns4 * 64,
                          hs_all + wave * stage_floats<KS, BQ>(), lane, myks, acc);
+      DBG_STAMP(2);  // gather + MFMA
     }
 #pragma unroll
     for (int bq = 0; bq < BQ; ++bq) *reinterpret_cast<f32x4*>(&part[((wave * BQ + bq) * 64 + lane) * 4]) = acc[bq];
     __syncthreads();
+    f32x4 dg4 = {0.f, 0.f, 0.f, 0.f};
     if (owner) {
       float dh = dyv;
 #pragma unroll
       for (int w = 0; w < 4; ++w)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) dh += part[((w * BQ + obq) * 64 + 4 * (ks * UQ + ouq) + ojb) * 4 + oi];
-      f32x4 dg4 = {0.f, 0.f, 0.f, 0.f};
       if (active) {
         const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
-        const float tc = tanhf(c_t);
+        const float tc = tanh_hw(c_t);
         const float dc = dh * og * (1.f - tc * tc) + dc_carry;
         dg4[0] = dc * gg * ig * (1.f - ig);
         dg4[1] = dc * c_p * fg * (1.f - fg);
@@ -674,11 +812,23 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
       } else {
         dc_carry = 0.f;
       }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dg4), gx_rsrc[s & 1], (brow * 4 * Kp + 4 * oj) * 4, 0, AUX_SC1);
-      if (valid) *reinterpret_cast<f32x4*>(p.gates + grow * 4 * H + 4 * oj) = dg4;
+      exchange_store<LOCAL>(__builtin_bit_cast(i32x4, dg4), gx_rsrc[s & 1], gx_off);
     }
-    publish_flag(flags + wg, (unsigned)(s + 1));
+    DBG_STAMP(3);  // LDS reduce + cell math + exchange store issue
+    publish_flag2<LOCAL>(flags + wg, (unsigned)(s + 1));
+    DBG_STAMP(4);  // drain + barrier + flag
+    if (valid) *reinterpret_cast<f32x4*>(p.gates + g_off) = dg4;  // stash after the flag (off the critical path)
+    g_off += g_step;
+    c_off += c_step;
+    y_off += y_step;
+    DBG_STAMP(5);  // stash stores issue
   }
+  return true;
+  };
+  const bool ok = local ? run(std::true_type{}) : run(std::false_type{});
+  if (!ok) return;
+  if (p.dbg && tid == 0)
+    for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -792,12 +942,13 @@ int device_cus() {
 
 struct LstmWs {
   unsigned* flags;  // [16 words: status at word 0] [D*NC step flags], zeroed per launch
-  size_t sync_bytes;
+  size_t sync_bytes, nflags;
   float* hx;
   size_t hx_bytes;
   float* wp;   // (D*4H, I) permuted input weights; reused as dW_ih' in backward
   float* bp;   // (D*4H)
   float* dwhh; // (D*4H, H) scratch for dW_hh'
+  unsigned long long* dbg;  // 256 workgroups x 8 phase counters (diagnostics)
   void* scratch;  // split-K slabs of the weight-gradient GEMMs / column-sum partials
   size_t scratch_bytes;
   size_t total;
@@ -885,13 +1036,15 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
       if (hx2 > hxb) hxb = hx2;
     }
   }
-  w.sync_bytes = align_up((nflags + 16) * 4, 16);
+  w.nflags = nflags;
+  w.sync_bytes = align_up((2 * nflags + 16) * 4, 16);  // status block | step flags | XCC table
   w.flags = reinterpret_cast<unsigned*>(take(w.sync_bytes));
   w.hx_bytes = hxb;
   w.hx = reinterpret_cast<float*>(take(w.hx_bytes));
   w.wp = reinterpret_cast<float*>(take((size_t)D * 4 * H * I * 4));
   w.bp = reinterpret_cast<float*>(take((size_t)D * 4 * H * 4));
   w.dwhh = reinterpret_cast<float*>(take((size_t)D * 4 * H * H * 4));
+  w.dbg = reinterpret_cast<unsigned long long*>(take(512 * 8 * 8));
   {
     const int64_t M = (int64_t)T * B, N4 = (int64_t)D * 4 * H;
     size_t sc = rnnt_hip_gemm_workspace_bytes(N4, I, M);
@@ -1001,6 +1154,10 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->w_hh[0] = d->w_hh[0]; k->w_hh[1] = d->D > 1 ? d->w_hh[1] : d->w_hh[0];
   k->hx = w.hx; k->status = w.flags; k->flags = w.flags + 16;
   k->dy = nullptr;
+  k->G = 1; k->Bg = d->B; k->Kp = d->H;
+  k->dbg = getenv("RNNT_LSTM_DBG") ? w.dbg : nullptr;
+  k->xcc = w.flags + 16 + w.nflags;
+  k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
 }
 
 }  // namespace
@@ -1173,6 +1330,18 @@ extern "C" int rnnt_hip_lstm_check(const void* workspace, void* stream) {
     set_error("persistent LSTM kernel abandoned an inter-workgroup wait (status %u)", st);
     return RNNT_ERR_TIMEOUT;
   }
+  return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_lstm_debug_read(const void* workspace, int32_t T, int32_t B, int32_t I, int32_t H, int32_t D,
+                                        uint64_t* out, int32_t nwg, void* stream) {
+  Plan pl;
+  int cus = device_cus();
+  RNNT_CHECK_ARG(workspace && out && nwg >= 1 && nwg <= 512, "lstm_debug_read: bad arguments");
+  RNNT_CHECK_ARG(make_plan(B, H, D, cus, &pl), "lstm_debug_read: unsupported shape");
+  const LstmWs w = carve_lstm(const_cast<void*>(workspace), T, B, I, H, D, pl);
+  RNNT_CHECK_HIP(hipMemcpyAsync(out, w.dbg, (size_t)nwg * 8 * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RNNT_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
   return RNNT_OK;
 }
 

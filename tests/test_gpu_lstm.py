@@ -117,3 +117,36 @@ def test_lstm_v1_fallback_kernels_still_match(monkeypatch, B, T, I, H, L, bi):
     H = 1024 with B > 16) stay covered: force them with RNNT_LSTM_V1=1."""
     monkeypatch.setenv("RNNT_LSTM_V1", "1")
     test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
+
+
+def test_xcd_local_exchange_is_bitwise_identical_to_write_through(monkeypatch):
+    """B=32, H=512, bidirectional -> 8 sync groups x 32 workgroups = the BASELINE config-2 decomposition.  When a group
+    is verified to sit on one XCD it exchanges through that XCD's L2 (plain stores); otherwise / when disabled it uses
+    the sc1 write-through protocol.  Same arithmetic either way: outputs and gradients must be bitwise equal, and
+    both must match the oracle."""
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    B, T, I, H = 32, 24, 16, 512
+    torch.manual_seed(3)
+    ref = nn.LSTM(I, H, 1, batch_first=True, bidirectional=True).double()
+    hip = HipLSTM(I, H, 1, bidirectional=True)
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hip = hip.cuda()
+    g = torch.Generator().manual_seed(5)
+    lens = [T] + torch.randint(1, T + 1, (B - 1,), generator=g).tolist()
+    x = torch.randn(B, T, I, generator=g)
+    dy = torch.randn(B, T, 2 * H, generator=g)
+    ref_out, ref_dx = _oracle(x, lens, ref, dy)
+    results = []
+    for disable in (False, True):
+        if disable:
+            monkeypatch.setenv("RNNT_LSTM_NO_XCD_LOCAL", "1")
+        hip.zero_grad()
+        x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
+        y = hip(x_tm, torch.tensor(lens, dtype=torch.int32, device="cuda"))
+        y.backward(dy.transpose(0, 1).contiguous().cuda())
+        torch.cuda.synchronize()
+        results.append((y.detach().clone(), x_tm.grad.clone(), hip.weight_hh_l0.grad.clone(), hip.weight_ih_l0_reverse.grad.clone()))
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    assert (results[0][0].transpose(0, 1).double().cpu() - ref_out).abs().max().item() < FWD_ATOL
+    assert (results[0][1].transpose(0, 1).double().cpu() - ref_dx).abs().max().item() < GRAD_RTOL * max(ref_dx.abs().max().item(), 1e-3) + 1e-6

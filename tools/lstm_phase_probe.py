@@ -1,0 +1,38 @@
+"""Diagnostic: per-phase cycle shares of one step of the v2 LSTM recurrences at BASELINE config 2 layer shapes.
+   RNNT_LSTM_DBG=1 python tools/lstm_phase_probe.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["RNNT_LSTM_DBG"] = "1"
+import numpy as np
+import torch
+from rnntransducer_amd import _lib
+from rnntransducer_amd.ops import LstmStackFn, _addr, _stream
+from rnntransducer_amd.networks.rnn import HipLSTM
+
+T, B, I, H = 1000, 32, 1024, 512
+torch.manual_seed(0)
+lstm = HipLSTM(I, H, 1, bidirectional=True).cuda()
+x = torch.randn(T, B, I, device="cuda", requires_grad=True)
+lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
+names = ["prefetch issue", "flag wait", "gather+MFMA", "reduce+cell math", "drain+barrier+flag", "stash stores"]
+
+class Hook:
+    pass
+
+def read(ws, tag):
+    out = np.zeros((256, 8), dtype=np.uint64)
+    _lib.check(_lib.lib().rnnt_hip_lstm_debug_read(_addr(ws), T, B, I, H, 2, out.ctypes.data, 256, _stream()), "dbg")
+    tot = out[:, :6].sum(1).astype(np.float64)
+    print(f"--- {tag}: cycles/step per phase (median over 256 workgroups; min..max), total {np.median(tot) / T:.0f} cyc/step")
+    for i, n in enumerate(names):
+        v = out[:, i].astype(np.float64) / T
+        print(f"   {n:22s} {np.median(v):8.0f}   ({v.min():.0f} .. {v.max():.0f})")
+
+for it in range(2):
+    y = lstm(x, lens)
+    torch.cuda.synchronize()
+ws = y.grad_fn.ws
+read(ws, "forward")
+y.backward(torch.randn_like(y))
+torch.cuda.synchronize()
+read(ws, "backward")
