@@ -697,8 +697,13 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
   };
   const bool ok = local ? run(std::true_type{}) : run(std::false_type{});
   if (!ok) return;
-  if (p.dbg && tid == 0)
+  if (p.dbg && tid == 0) {
     for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    p.dbg[blockIdx.x * 8 + 6] = local ? 1 : 0;
+    p.dbg[blockIdx.x * 8 + 7] = xcc_id & 0xf;
+  }
 }
 
 // dynamic LDS: WA[4][Ls/4][64] f32x4 | hs[4][stage_floats] | part[4][BQ][64] f32x4 | abort
@@ -827,8 +832,13 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
   };
   const bool ok = local ? run(std::true_type{}) : run(std::false_type{});
   if (!ok) return;
-  if (p.dbg && tid == 0)
+  if (p.dbg && tid == 0) {
     for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    p.dbg[blockIdx.x * 8 + 6] = local ? 1 : 0;
+    p.dbg[blockIdx.x * 8 + 7] = xcc_id & 0xf;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

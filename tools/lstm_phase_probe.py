@@ -24,6 +24,7 @@ def read(ws, tag):
     _lib.check(_lib.lib().rnnt_hip_lstm_debug_read(_addr(ws), T, B, I, H, 2, out.ctypes.data, 256, _stream()), "dbg")
     tot = out[:, :6].sum(1).astype(np.float64)
     print(f"--- {tag}: cycles/step per phase (median over 256 workgroups; min..max), total {np.median(tot) / T:.0f} cyc/step")
+    print(f"   xcd-local groups: {int(out[:, 6].sum())}/256 workgroups; XCC ids of blocks 0..15: {out[:16, 7].astype(int).tolist()}")
     for i, n in enumerate(names):
         v = out[:, i].astype(np.float64) / T
         print(f"   {n:22s} {np.median(v):8.0f}   ({v.min():.0f} .. {v.max():.0f})")
