@@ -103,7 +103,7 @@ def main():
 
     cfg = CONFIGS[a.config]
     B, T, U, V = cfg[:4]
-    model, tn, pn = build_model(cfg, a.dropout, a.warmup + a.steps + 1)
+    model, tn, pn = build_model(cfg, a.dropout, max(100, a.warmup + a.steps + 1))
     model = model.to(dev).train()
     batch = synthetic_batch(B, T, U, V, ragged=a.ragged, seed=1234 + rank, device=dev)
     conf = model.configure_optimizers()
