@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--ragged", action="store_true", help="KsponSpeech-shaped ragged lengths (SURVEY §8d c4 variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="utterances in the CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16)
     a = ap.parse_args()
 
@@ -136,7 +136,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     L.rnnt_hip_prof_enable(0)
-    last_loss = float(loss)
+    last_loss = float(loss.detach())
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -164,6 +164,15 @@ def main():
         achieved = kd["work_per_launch"] / per_launch_s / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None}
+    # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
+    # MI355X_MICROARCH.md prescribes); collected offline because counters cannot be read from inside the process
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+        if pmc.get("config") == a.config:
+            roof["traffic"] = round(pmc["hbm_bytes_per_launch"][dom])
+            roof["traffic_source"] = pmc["from"]
+    except (OSError, KeyError, ValueError):
+        pass
     roof["avg_launch_us"] = kd["avg_us"]
     roof["launches"] = kd["launches"]
 
