@@ -9,11 +9,13 @@
 // conflict-free, ds_write_b128 stays 16-B aligned), register-prefetch double buffering.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace rnnt {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+constexpr int BM = 128, BK = 16, LDT = 132;
 
 struct GemmK {
   int M, N, K;
@@ -36,11 +38,15 @@ struct GemmK {
 // Loads this thread's share (2 x 4 floats) of a (128 rows) x (16 k) operand tile and parks it in LDS K-major.
 // KC: operand rows are k-contiguous in memory (row r at rowptr[r], element k at +k).
 // !KC: operand is r-contiguous (element (r,k) at base + k*sk + r).
-template <bool KC, bool VEC4>
+template <bool KC, bool VEC4, int ROWS>
 struct TileIO {
-  f32x4 v[2];
+  static constexpr int NP = ROWS / 64;          // float4 per thread per K-tile
+  static constexpr int LD = ROWS + 4;           // LDS row stride (floats) of the K-major image
+  static constexpr int TPR = ROWS / 4;          // !KC: threads per k-row
+  static constexpr int KPP = 256 / TPR;         // !KC: k-rows per pass
+  f32x4 v[NP];
   // KC state
-  const float* rowptr[2];
+  const float* rowptr[NP];
   // !KC state
   const float* base;
   long sk;
@@ -50,7 +56,7 @@ struct TileIO {
   __device__ __forceinline__ void load(int k0) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       f32x4 x = {0.f, 0.f, 0.f, 0.f};
       if constexpr (KC) {
         const int k = k0 + 4 * (tid & 3);
@@ -65,8 +71,8 @@ struct TileIO {
           }
         }
       } else {
-        const int k = k0 + (tid >> 5) + 8 * p;
-        const int r = r0 + 4 * (tid & 31);
+        const int k = k0 + tid / TPR + KPP * p;
+        const int r = r0 + 4 * (tid % TPR);
         if (k < K) {
           const float* src = base + (long)k * sk + r;
           if (VEC4 && r + 3 < R) {
@@ -89,24 +95,27 @@ struct TileIO {
   __device__ __forceinline__ void store(float* S) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       if constexpr (KC) {
         const int rl = (tid >> 2) + 64 * p;
         const int kq = 4 * (tid & 3);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) S[(kq + e) * LDT + rl] = v[p][e];
+        for (int e = 0; e < 4; ++e) S[(kq + e) * LD + rl] = v[p][e];
       } else {
-        const int kl = (tid >> 5) + 8 * p;
-        *reinterpret_cast<f32x4*>(&S[kl * LDT + 4 * (tid & 31)]) = v[p];
+        const int kl = tid / TPR + KPP * p;
+        *reinterpret_cast<f32x4*>(&S[kl * LD + 4 * (tid % TPR)]) = v[p];
       }
     }
   }
 };
 
-template <bool A_KC, bool B_KC, bool VEC4>
-__global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
+// NW = 32-wide N tiles per wave: 2 -> 128x128 block tile, 4 -> 128x256 (each wave 64x128: 8 MFMAs per operand fetch,
+// 25% fewer operand bytes per FLOP; used when N is wide enough)
+template <bool A_KC, bool B_KC, bool VEC4, int NW>
+__global__ void __launch_bounds__(256, (NW == 4 ? 2 : 3)) gemm_f32_kernel(const GemmK p) {
+  constexpr int BN = 64 * NW, LDB = BN + 4;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -123,8 +132,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
   }
   const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
 
-  TileIO<A_KC, VEC4> ta;
-  TileIO<B_KC, VEC4> tb;
+  TileIO<A_KC, VEC4, BM> ta;
+  TileIO<B_KC, VEC4, BN> tb;
   ta.K = tb.K = p.K;
   ta.gelu = (p.flags & RNNT_GEMM_GELU_A) != 0;
   tb.gelu = (p.flags & RNNT_GEMM_GELU_B) != 0;
@@ -147,7 +156,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
   }
   if constexpr (B_KC) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < BN / 64; ++q) {
       const int n = n0 + (tid >> 2) + 64 * q;
       tb.rowptr[q] = n < p.N ? p.B + (long)n * p.b_sn : nullptr;
     }
@@ -158,11 +167,11 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
     tb.R = p.N;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NW; ++j)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
@@ -177,28 +186,50 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
   __syncthreads();
 
   const int aoff = (lane >> 5) * LDT + wm * 64 + (lane & 31);
-  const int boff = (lane >> 5) * LDT + wn * 64 + (lane & 31);
+  const int boff = (lane >> 5) * LDB + wn * (32 * NW) + (lane & 31);
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      ta.load(kbeg + (kt + 1) * BK);
-      tb.load(kbeg + (kt + 1) * BK);
-    }
+    ta.load(kbeg + (kt + 1) * BK);  // past the last tile every element is predicated off (k >= kend): no access, zeros
+    tb.load(kbeg + (kt + 1) * BK);
     const float* as = As[cur] + aoff;
     const float* bs = Bs[cur] + boff;
+    // all of this K-tile's operands first (32 VGPRs), then 32 MFMAs back to back: the LDS latency is exposed once per
+    // K-tile instead of once per 4 MFMAs (the other waves of the SIMD cover that one)
+    // Two batches of 4 k-pairs.  Batch 0: operand reads, then its MFMAs (the next tile's global loads, issued above,
+    // land meanwhile).  Batch 1: operand reads, then its MFMAs with the next tile's LDS stores slotted between them
+    // (other LDS buffer, no hazard): the vmcnt wait and the store pass ride in the MFMA shadow instead of forming
+    // their own phase in front of the barrier.
+    constexpr int KH = 4;
 #pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-      const float a0 = as[2 * kp * LDT], a1 = as[2 * kp * LDT + 32];
-      const float b0 = bs[2 * kp * LDT], b1 = bs[2 * kp * LDT + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      ta.store(As[cur ^ 1]);
-      tb.store(Bs[cur ^ 1]);
+    for (int kb = 0; kb < BK / 2; kb += KH) {
+      float av[KH][2], bv[KH][NW];
+#pragma unroll
+      for (int kp = 0; kp < KH; ++kp) {
+        av[kp][0] = as[2 * (kb + kp) * LDT];
+        av[kp][1] = as[2 * (kb + kp) * LDT + 32];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) bv[kp][j] = bs[2 * (kb + kp) * LDB + 32 * j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kp = 0; kp < KH; ++kp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][i], bv[kp][j], acc[i][j], 0, 0, 0);
+      if (kb + KH >= BK / 2) {
+        ta.store(As[cur ^ 1]);  // unconditional (straight-line body): after the last tile this parks zeros/stale data in
+        tb.store(Bs[cur ^ 1]);  // the buffer nobody reads again
+        // schedule: 2 MFMAs, then one DS write, repeated; the remaining MFMAs follow
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
@@ -213,8 +244,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
         const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NW; ++j) {
+          const int n = n0 + wn * (32 * NW) + j * 32 + (lane & 31);
           if (n < p.N) slab[(long)m * p.N + n] = acc[i][j][v];
         }
       }
@@ -229,8 +260,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const GemmK p) {
       if (m >= p.M) continue;
       const long rowoff = (long)(m / p.c_div) * p.c_so + (long)(m % p.c_div) * p.c_si;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      for (int j = 0; j < NW; ++j) {
+        const int n = n0 + wn * (32 * NW) + j * 32 + (lane & 31);
         if (n >= p.N) continue;
         float val = acc[i][j][v];
         if (p.bias) val += p.bias[n];
@@ -258,6 +289,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK p) {
   }
 }
 
+// 128x256 tiles when N is wide and the grid still has plenty of tiles; 128x128 otherwise
+inline int pick_bn(int64_t M, int64_t N) {
+  if (getenv("RNNT_GEMM_BN128")) return 128;
+  return (N >= 256 && N % 256 == 0 && ceil_div(M, BM) * (N / 256) >= 64) ? 256 : 128;
+}
+
 inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
 }  // namespace
@@ -267,7 +304,7 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 extern "C" size_t rnnt_hip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   // enough for the split count rnnt_hip_gemm_f32 would pick; 0 when it would not split
   if (M <= 0 || N <= 0 || K < 8 * rnnt::BK) return 0;
-  const long tiles = rnnt::ceil_div(M, rnnt::BM) * rnnt::ceil_div(N, rnnt::BN);
+  const long tiles = rnnt::ceil_div(M, rnnt::BM) * rnnt::ceil_div(N, rnnt::pick_bn(M, N));
   if (tiles >= 512) return 0;
   long want = rnnt::ceil_div(1024, tiles);
   const long by_k = K / (8 * rnnt::BK);
@@ -309,7 +346,8 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   if (b_kc) vec = vec && (d->b_sn % 4 == 0);
   else vec = vec && (d->b_sk % 4 == 0);
 
-  const int tiles = (int)(ceil_div(d->M, BM) * ceil_div(d->N, BN));
+  const int bn = pick_bn(d->M, d->N);
+  const int tiles = (int)(ceil_div(d->M, BM) * ceil_div(d->N, bn));
   // split-K when the output has too few tiles to fill 256 CUs and K is deep (weight-gradient GEMMs):
   // partial slabs in the caller's workspace, summed in fixed order (bitwise reproducible; no float atomics)
   int splits = 1;
@@ -329,7 +367,11 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   dim3 grid(tiles, splits), block(256);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(RNNT_K_GEMM, 2.0 * (double)d->M * (double)d->N * (double)d->K, s);
-#define LAUNCH(AK, BKC, V) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, V>), grid, block, 0, s, k)
+#define LAUNCH(AK, BKC, V)                                                                      \
+  do {                                                                                          \
+    if (bn == 256) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, V, 4>), grid, block, 0, s, k);  \
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, V, 2>), grid, block, 0, s, k);            \
+  } while (0)
   if (a_kc && b_kc) { if (vec) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
   else if (a_kc && !b_kc) { if (vec) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
   else if (!a_kc && b_kc) { if (vec) LAUNCH(false, true, true); else LAUNCH(false, true, false); }

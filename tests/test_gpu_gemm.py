@@ -17,7 +17,7 @@ def gelu64(x):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (130, 70, 33), (257, 129, 80), (512, 256, 1024), (1000, 72, 512), (64, 2048, 640),
-                                   (37, 10, 16), (5, 3, 7)])
+                                   (37, 10, 16), (5, 3, 7), (2048, 1024, 96), (2100, 768, 40)])
 @pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
 def test_gemm_modes(M, N, K, mode):
     from rnntransducer_amd.ops import gemm
