@@ -183,6 +183,16 @@ int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int32_t* labels
  * construction, nn.Embedding(padding_idx=blank)). */
 int rnnt_hip_embedding_fwd(const float* W, const int64_t* idx, int64_t M, int32_t H, int32_t V, float* out, void* stream);
 
+/* Same, for logits/grad stored as fp16 or bf16 (torchaudio's RNNTLoss takes half logits: model.py:28-31); the
+ * log-softmax, alpha/beta and gradient arithmetic stay fp32/fp64, only loads/stores convert. */
+#define RNNT_DTYPE_F32 0
+#define RNNT_DTYPE_F16 1
+#define RNNT_DTYPE_BF16 2
+int rnnt_hip_loss_from_logits_fwd_bwd_ex(const void* logits, int32_t dtype, const int32_t* labels, const int32_t* t_lens,
+                                         const int32_t* u_lens, int32_t B, int32_t T, int32_t U1, int32_t V, int32_t blank,
+                                         float gscale, float* nll, void* grad, void* workspace, size_t workspace_bytes,
+                                         void* stream);
+
 /* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients: fc.bias, out_proj.bias, LSTM biases).
  * Two-stage fixed-order reduction; workspace = rnnt_hip_colsum_workspace_bytes(M, N) bytes. */
 size_t rnnt_hip_colsum_workspace_bytes(int64_t M, int64_t N);

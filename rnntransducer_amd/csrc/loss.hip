@@ -17,10 +17,22 @@
 //   grad_dense_kernel                 : warp-transducer-shaped d/d logits for rnnt_hip_loss_from_logits_*
 #include "common.hpp"
 
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
 namespace rnnt {
 namespace {
 
 constexpr int TT = 32;  // frames per workgroup tile
+
+// dense-logits entry points accept fp32, fp16 or bf16 storage (torchaudio's RNNTLoss takes half logits, model.py:28-31);
+// all arithmetic stays fp32 / fp64
+__device__ __forceinline__ float ldf(const float* p, long i) { return p[i]; }
+__device__ __forceinline__ float ldf(const __half* p, long i) { return __half2float(p[i]); }
+__device__ __forceinline__ float ldf(const __hip_bfloat16* p, long i) { return __bfloat162float(p[i]); }
+__device__ __forceinline__ void stf(float* p, long i, float v) { p[i] = v; }
+__device__ __forceinline__ void stf(__half* p, long i, float v) { p[i] = __float2half(v); }
+__device__ __forceinline__ void stf(__hip_bfloat16* p, long i, float v) { p[i] = __float2bfloat16(v); }
 constexpr double NEG_INF = -__builtin_huge_val();
 
 __device__ __forceinline__ float wave_max(float x) {
@@ -88,19 +100,20 @@ __global__ void __launch_bounds__(256) lse_sep_kernel(const float* __restrict__ 
 }
 
 // dense logits (B,T,U1,V): one wavefront per cell, lanes along v, grid-stride over cells
-__global__ void __launch_bounds__(256) lse_dense_kernel(const float* __restrict__ Z, const int* __restrict__ labels,
+template <typename TZ>
+__global__ void __launch_bounds__(256) lse_dense_kernel(const TZ* __restrict__ Z, const int* __restrict__ labels,
                                                         int B, int T, int U1, int V, int blank,
                                                         float* __restrict__ blk, float* __restrict__ emit) {
   const int lane = threadIdx.x & 63;
   const long ncell = (long)B * T * U1;
   const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
   for (long cell = wave0; cell < ncell; cell += nw) {
-    const float* z = Z + cell * V;
+    const TZ* z = Z + cell * V;
     float m = -__builtin_huge_valf();
-    for (int v = lane; v < V; v += 64) m = fmaxf(m, z[v]);
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, ldf(z, v));
     m = wave_max(m);
     float s = 0.f;
-    for (int v = lane; v < V; v += 64) s += expf(z[v] - m);
+    for (int v = lane; v < V; v += 64) s += expf(ldf(z, v) - m);
     s = wave_sum(s);
     if (lane == 0) {
       const int u = (int)(cell % U1);
@@ -108,8 +121,8 @@ __global__ void __launch_bounds__(256) lse_dense_kernel(const float* __restrict_
       const int t = (int)(bt % T), b = (int)(bt / T);
       const float lse = m + logf(s);
       const long o = ((long)b * U1 + u) * T + t;
-      blk[o] = z[blank] - lse;
-      emit[o] = (u < U1 - 1) ? z[labels[(long)b * (U1 - 1) + u]] - lse : 0.f;
+      blk[o] = ldf(z, blank) - lse;
+      emit[o] = (u < U1 - 1) ? ldf(z, labels[(long)b * (U1 - 1) + u]) - lse : 0.f;
     }
   }
 }
@@ -349,12 +362,13 @@ __global__ void __launch_bounds__(256) reduce_dc_kernel(const float* __restrict_
 }
 
 // dense d/d logits: one wavefront per cell
-__global__ void __launch_bounds__(256) grad_dense_kernel(const float* __restrict__ Z, const int* __restrict__ labels,
+template <typename TZ>
+__global__ void __launch_bounds__(256) grad_dense_kernel(const TZ* __restrict__ Z, const int* __restrict__ labels,
                                                          const int* __restrict__ t_lens, const int* __restrict__ u_lens,
                                                          const float* __restrict__ blk, const float* __restrict__ emit,
                                                          const double* __restrict__ alpha, const double* __restrict__ beta,
                                                          const double* __restrict__ ll, int B, int T, int U1, int V,
-                                                         int blank, float gscale, float* __restrict__ G) {
+                                                         int blank, float gscale, TZ* __restrict__ G) {
   const int lane = threadIdx.x & 63;
   const long ncell = (long)B * T * U1;
   const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
@@ -363,19 +377,19 @@ __global__ void __launch_bounds__(256) grad_dense_kernel(const float* __restrict
     const long bt = cell / U1;
     const int t = (int)(bt % T), b = (int)(bt / T);
     const int Tb = t_lens[b], Ub = u_lens[b];
-    const float* z = Z + cell * V;
-    float* g = G + cell * V;
+    const TZ* z = Z + cell * V;
+    TZ* g = G + cell * V;
     if (t >= Tb || u > Ub) {
-      for (int v = lane; v < V; v += 64) g[v] = 0.f;
+      for (int v = lane; v < V; v += 64) stf(g, v, 0.f);
       continue;
     }
-    const CellS c = cell_scalars(blk, emit, alpha, beta, (long)b * U1 * T, T, t, u, Tb, Ub, ll[b], z[blank]);
+    const CellS c = cell_scalars(blk, emit, alpha, beta, (long)b * U1 * T, T, t, u, Tb, Ub, ll[b], ldf(z, blank));
     const int y = (u < U1 - 1) ? labels[(long)b * (U1 - 1) + u] : -1;
     for (int v = lane; v < V; v += 64) {
-      float x = c.w * expf(z[v] - c.lse);
+      float x = c.w * expf(ldf(z, v) - c.lse);
       if (v == blank) x -= c.cb;
       if (v == y && u < Ub) x -= c.ce;
-      g[v] = x * gscale;
+      stf(g, v, x * gscale);
     }
   }
 }
@@ -513,10 +527,10 @@ extern "C" int rnnt_hip_joint_logits_fwd(const float* A, int64_t a_sb, int64_t a
   return RNNT_OK;
 }
 
-extern "C" int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int32_t* labels, const int32_t* t_lens,
-                                                 const int32_t* u_lens, int32_t B, int32_t T, int32_t U1, int32_t V,
-                                                 int32_t blank, float gscale, float* nll, float* grad, void* workspace,
-                                                 size_t workspace_bytes, void* stream) {
+template <typename TZ>
+static int loss_from_logits_impl(const void* logits, const int32_t* labels, const int32_t* t_lens, const int32_t* u_lens,
+                                 int32_t B, int32_t T, int32_t U1, int32_t V, int32_t blank, float gscale, float* nll,
+                                 void* grad, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_common(labels, t_lens, u_lens, B, T, U1, V, blank, nll)) return rc;
   RNNT_CHECK_ARG(logits, "loss_from_logits: null logits");
   const LossWs w = carve(workspace, B, T, U1, V, true);
@@ -525,18 +539,43 @@ extern "C" int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int3
   const long ncell = (long)B * T * U1;
   const unsigned grid = (unsigned)(ceil_div(ncell, 4) < 16384 ? ceil_div(ncell, 4) : 16384);
   {
-  ProfScope prof(RNNT_K_LSE, 4.0 * (double)ncell * V + 8.0 * (double)ncell, s);
-  hipLaunchKernelGGL(lse_dense_kernel, dim3(grid), dim3(256), 0, s, logits, labels, B, T, U1, V, blank, w.blk, w.emit);
+  ProfScope prof(RNNT_K_LSE, (double)sizeof(TZ) * (double)ncell * V + 8.0 * (double)ncell, s);
+  hipLaunchKernelGGL((lse_dense_kernel<TZ>), dim3(grid), dim3(256), 0, s, (const TZ*)logits, labels, B, T, U1, V, blank, w.blk, w.emit);
   }
   RNNT_CHECK_LAUNCH();
   if (int rc = launch_alphabeta(w, t_lens, u_lens, B, T, U1, s)) return rc;
   hipLaunchKernelGGL(nll_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, w.ll, B, nll);
   RNNT_CHECK_LAUNCH();
   if (grad) {
-    ProfScope prof(RNNT_K_LATGRAD, 8.0 * (double)ncell * V + 24.0 * (double)ncell, s);
-    hipLaunchKernelGGL(grad_dense_kernel, dim3(grid), dim3(256), 0, s, logits, labels, t_lens, u_lens, w.blk, w.emit,
-                       w.alpha, w.beta, w.ll, B, T, U1, V, blank, gscale, grad);
+    ProfScope prof(RNNT_K_LATGRAD, 2.0 * sizeof(TZ) * (double)ncell * V + 24.0 * (double)ncell, s);
+    hipLaunchKernelGGL((grad_dense_kernel<TZ>), dim3(grid), dim3(256), 0, s, (const TZ*)logits, labels, t_lens, u_lens, w.blk, w.emit,
+                       w.alpha, w.beta, w.ll, B, T, U1, V, blank, gscale, (TZ*)grad);
     RNNT_CHECK_LAUNCH();
   }
   return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_loss_from_logits_fwd_bwd_ex(const void* logits, int32_t dtype, const int32_t* labels,
+                                                    const int32_t* t_lens, const int32_t* u_lens, int32_t B, int32_t T,
+                                                    int32_t U1, int32_t V, int32_t blank, float gscale, float* nll, void* grad,
+                                                    void* workspace, size_t workspace_bytes, void* stream) {
+  switch (dtype) {
+    case RNNT_DTYPE_F32:
+      return loss_from_logits_impl<float>(logits, labels, t_lens, u_lens, B, T, U1, V, blank, gscale, nll, grad, workspace, workspace_bytes, stream);
+    case RNNT_DTYPE_F16:
+      return loss_from_logits_impl<__half>(logits, labels, t_lens, u_lens, B, T, U1, V, blank, gscale, nll, grad, workspace, workspace_bytes, stream);
+    case RNNT_DTYPE_BF16:
+      return loss_from_logits_impl<__hip_bfloat16>(logits, labels, t_lens, u_lens, B, T, U1, V, blank, gscale, nll, grad, workspace, workspace_bytes, stream);
+    default:
+      set_error("loss_from_logits: unknown dtype code %d", dtype);
+      return RNNT_ERR_INVALID;
+  }
+}
+
+extern "C" int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int32_t* labels, const int32_t* t_lens,
+                                                 const int32_t* u_lens, int32_t B, int32_t T, int32_t U1, int32_t V,
+                                                 int32_t blank, float gscale, float* nll, float* grad, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  return rnnt_hip_loss_from_logits_fwd_bwd_ex(logits, RNNT_DTYPE_F32, labels, t_lens, u_lens, B, T, U1, V, blank, gscale, nll, grad,
+                                              workspace, workspace_bytes, stream);
 }

@@ -44,7 +44,19 @@ class RNNTransducer(_Base):
         self.rnnt_loss = RNNTLoss(blank=self.blank_token_id, reduction="mean")
 
     def forward(self, input_audios, audio_lengths, input_texts, text_lengths):
+        # the reference hands these two as python lists (dataloader.py:20,37): validating them costs no device sync
+        if isinstance(audio_lengths, (list, tuple)) and (max(audio_lengths) > input_audios.size(1) or min(audio_lengths) < 1):
+            raise ValueError(f"audio_lengths must lie in [1, {input_audios.size(1)}]")
+        if isinstance(text_lengths, (list, tuple)) and (max(text_lengths) > input_texts.size(1) or min(text_lengths) < 1):
+            raise ValueError(f"text_lengths must lie in [1, {input_texts.size(1)}]")
         return self.jointnet(input_audios, audio_lengths, input_texts, text_lengths)
+
+    def load_reference_checkpoint(self, path: str, strict: bool = True):
+        """Loads the `state_dict` of a Lightning .ckpt written by the reference trainer (train.py:31-37; keys
+        `jointnet.*`).  Uses torch.load(weights_only=True): nothing from the file is executed."""
+        blob = torch.load(path, map_location="cpu", weights_only=True)
+        sd = blob.get("state_dict", blob)
+        return self.load_state_dict({k: v for k, v in sd.items() if k.startswith("jointnet.")}, strict=strict)
 
     def training_step(self, batch, batch_idx):
         assert not getattr(self.args, "move_metrics_to_cpu", False), "DDP only (model.py:53)"

@@ -359,7 +359,10 @@ class RnntLossFromLogitsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, t_lens, u_lens, blank):
         _need_gpu(logits, targets, t_lens, u_lens)
-        logits = _f32c(logits, "logits")
+        codes = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+        if logits.dtype not in codes:
+            raise ValueError(f"logits must be float32, float16 or bfloat16, got {logits.dtype}")
+        logits = logits if logits.is_contiguous() else logits.contiguous()
         for name, t in (("targets", targets), ("logit lengths", t_lens), ("target lengths", u_lens)):
             if t.dtype != torch.int32:
                 raise ValueError(f"{name} must be int32, got {t.dtype}")
@@ -371,9 +374,10 @@ class RnntLossFromLogitsFn(torch.autograd.Function):
         grad = torch.empty_like(logits) if logits.requires_grad else None
         nws = _lib.lib().rnnt_hip_joint_loss_workspace_bytes(B, T, U1, V)
         ws = torch.empty(nws, device=logits.device, dtype=torch.uint8)
-        check(_lib.lib().rnnt_hip_loss_from_logits_fwd_bwd(_addr(logits), _addr(targets), _addr(t_lens), _addr(u_lens), B, T,
-                                                           U1, V, int(blank), 1.0, _addr(nll), _addr(grad), _addr(ws), nws,
-                                                           _stream()), "rnnt_hip_loss_from_logits_fwd_bwd")
+        check(_lib.lib().rnnt_hip_loss_from_logits_fwd_bwd_ex(_addr(logits), codes[logits.dtype], _addr(targets), _addr(t_lens),
+                                                              _addr(u_lens), B, T, U1, V, int(blank), 1.0, _addr(nll),
+                                                              _addr(grad), _addr(ws), nws, _stream()),
+              "rnnt_hip_loss_from_logits_fwd_bwd_ex")
         ctx.grad = grad
         return nll
 
@@ -381,4 +385,4 @@ class RnntLossFromLogitsFn(torch.autograd.Function):
     def backward(ctx, g):
         grad = ctx.grad
         ctx.grad = None
-        return grad * g.to(torch.float32).view(-1, 1, 1, 1), None, None, None, None
+        return (grad.float() * g.to(torch.float32).view(-1, 1, 1, 1)).to(grad.dtype), None, None, None, None

@@ -65,3 +65,27 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 hit = re.search(r"^\s*(from|import)\s+oracle|oracle[/.]\w|librnnt_oracle", src, re.M)
                 assert hit is None, f"{f} reaches into oracle/: {hit.group(0)!r}"
+
+
+def test_reference_style_checkpoint_round_trip(tmp_path):
+    """A Lightning-style .ckpt ({"state_dict": {"jointnet....": tensor}, ...}) written with the reference's key names loads
+    into the HIP module unchanged (SURVEY.md §8b parameter names/layouts)."""
+    from rnntransducer_amd import RNNTransducer
+    args = Namespace(learning_rate=1e-3, weight_decay=1e-4, warmup_ratio=0.2, final_div_factor=1e4, total_steps=10)
+    cfg = (dict(embedding_size=10, hidden_size=8, output_size=8, num_layers=2), dict(input_size=12, hidden_size=8, output_size=8, num_layers=2),
+           dict(num_classes=10))
+    torch.manual_seed(1)
+    ref_like = torch.nn.ModuleDict({"encoder_rnn": torch.nn.LSTM(12, 8, 2, bidirectional=True), "decoder_rnn": torch.nn.LSTM(8, 8, 2)})
+    a = RNNTransducer(*cfg, args)
+    sd = {k: torch.randn_like(v) for k, v in a.state_dict().items()}
+    # torch.nn.LSTM (what the reference instantiates) uses exactly these names/shapes for the recurrent weights
+    for k, v in ref_like["encoder_rnn"].state_dict().items():
+        assert sd["jointnet.encoder.rnn." + k].shape == v.shape
+    for k, v in ref_like["decoder_rnn"].state_dict().items():
+        assert sd["jointnet.decoder.rnn." + k].shape == v.shape
+    path = tmp_path / "ref.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": {"x": 1}, "epoch": 3}, path)
+    b = RNNTransducer(*cfg, args)
+    b.load_reference_checkpoint(str(path))
+    for k, v in b.state_dict().items():
+        assert torch.equal(v, sd[k]), k

@@ -1,0 +1,35 @@
+"""bench.py contract (driver reads this JSON line) on the tiny BASELINE config 1, and __graft_entry__.smoke()."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_emits_one_contract_line_with_roofline_and_cpu_baseline():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "3", "--warmup", "1",
+                          "--cpu-sample", "2", "--cpu-threads", "4"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["metric"] == "utterances/sec" and j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "weak"
+    assert j["dtype"] == "f32" and j["vs_baseline"] is None and j["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+    assert abs(j["roofline"]["frac"] - j["roofline"]["achieved"] / j["roofline"]["peak"]) < 1e-3
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 4 and j["cpu_baseline"]["value"] > 0
+    assert j["loss_rel_delta"] < 1e-4          # north_star tolerance on the whole path (mel, label) -> loss
+    assert "workload" in j["config"] and "model" not in j["config"]
+
+
+def test_smoke_entry_point():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.smoke()

@@ -128,3 +128,23 @@ def test_loss_rejects_bad_dtypes_and_shapes():
         RNNTLoss()(z, torch.zeros(1, 1, dtype=torch.int64, device="cuda"), t, t)
     with pytest.raises(ValueError):
         RNNTLoss()(z, torch.zeros(1, 5, dtype=torch.int32, device="cuda"), t, t)
+
+
+@pytest.mark.parametrize("dtype,grad_tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
+def test_half_precision_logits_like_torchaudio_loss(dtype, grad_tol):
+    """the precision-16 branch (model.py:28-31) hands half logits to the loss.  Storage converts, arithmetic
+    stays fp32/fp64: NLL must equal the fp32 kernel run on the same (rounded) logits; grads are rounded to the dtype."""
+    from rnntransducer_amd.loss import RNNTLoss
+    rng = np.random.default_rng(11)
+    B, T, U, V = 3, 40, 9, 72
+    z = torch.tensor(rng.normal(size=(B, T, U + 1, V)), dtype=dtype)
+    y = torch.tensor(rng.integers(1, V, size=(B, U)), dtype=torch.int32)
+    t_lens, u_lens = [40, 33, 7], [9, 4, 0]
+    ref_nll, ref_grad = rnnt_loss_c(z.double().numpy(), y.numpy(), t_lens, u_lens, 0)
+    zg = z.cuda().requires_grad_(True)
+    loss = RNNTLoss(0, "sum")(zg, y.cuda(), torch.tensor(t_lens, dtype=torch.int32, device="cuda"),
+                              torch.tensor(u_lens, dtype=torch.int32, device="cuda"))
+    loss.backward()
+    assert abs(loss.item() - ref_nll.sum()) / ref_nll.sum() < 1e-5
+    assert zg.grad.dtype == dtype
+    assert np.abs(zg.grad.float().cpu().numpy() - ref_grad).max() < grad_tol
