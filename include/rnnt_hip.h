@@ -102,15 +102,22 @@ int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream);
  * Layouts: x (T,B,I) time-major [or any (x_st, x_sb) element strides], y (T,B,D*H) time-major.
  *   Frames t >= lens[b] produce y == 0 and contribute no gradient (pad_packed_sequence semantics,
  *   encoder.py:101); the reverse direction starts at each sequence's own last valid frame.
- *   Weights in torch layout: w_ih[d] (4H,I), w_hh[d] (4H,H), b_ih[d], b_hh[d] (4H), gate order i,f,g,o.
+ *   Weights in torch layout: w_ih[d] (G*H,I), w_hh[d] (G*H,H), b_ih[d], b_hh[d] (G*H); G = 4 (LSTM: i,f,g,o),
+ *   3 (GRU: r,z,n), 1 (Elman RNN).  The gate buffer always has 4 slots per hidden unit.
  *   Requirements: H % 4 == 0, D in {1,2}, B <= 64 per call, T >= 1.
  *
  * Stash written by fwd and consumed by bwd (caller-owned, sizes below):
  *   gates: D*T*B*4H floats ... activated gates, overwritten with dG by bwd
  *   cst  : D*T*B*H  floats ... cell states
  * ---------------------------------------------------------------------------------------------- */
+#define RNNT_CELL_LSTM 0      /* gates i,f,g,o   weights (4H, .)                                        */
+#define RNNT_CELL_GRU 1       /* gates r,z,n     weights (3H, .)  (torch.nn.GRU layout and equations)    */
+#define RNNT_CELL_RNN_TANH 2  /* Elman           weights (H, .)                                          */
+#define RNNT_CELL_RNN_RELU 3
+
 typedef struct rnnt_lstm_desc {
   int32_t T, B, I, H, D;
+  int32_t cell;        /* RNNT_CELL_*: the reference's supported_rnns = lstm | gru | rnn (encoder.py:48-52) */
   const int32_t* lens; /* (B) device */
   const float* x;
   int64_t x_st, x_sb; /* element strides of x over t and b (feature stride 1) */
@@ -123,7 +130,8 @@ typedef struct rnnt_lstm_desc {
   float dropout_p;
   uint64_t dropout_seed;
   float* gates;   /* (T,B,D*4H) permuted gate layout, see DESIGN.md */
-  float* cst;     /* (D,T,H/4,B,4) */
+  float* cst;     /* (D,T,H/4,B,4)  LSTM only (may be NULL for the other cells) */
+  float* aux;     /* GRU backward only: (T,B,D*4H) scratch for the hidden-side gate gradients; else NULL */
   void* workspace;
   size_t workspace_bytes;
 } rnnt_lstm_desc;
@@ -137,7 +145,8 @@ typedef struct rnnt_lstm_bwd_desc {
   float* dx;          /* (T,B,I) time-major, or NULL (first layer: dataloader.py gives no grad to mel) */
   float* dw_ih[2];    /* (4H,I)  written (not accumulated) */
   float* dw_hh[2];    /* (4H,H) */
-  float* db[2];       /* (4H)   gradient of b_ih == gradient of b_hh */
+  float* db[2];       /* (G*H)  gradient of b_ih (== gradient of b_hh for LSTM / RNN) */
+  float* db_hh[2];    /* (3H)   GRU only: gradient of b_hh (differs from b_ih in the n gate); else NULL */
 } rnnt_lstm_bwd_desc;
 
 int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* d, void* stream);

@@ -159,7 +159,7 @@ def rnnt_loss_mean(logits, targets, t_lens, u_lens, blank: int = 0) -> torch.Ten
 # ----------------------------------------------------------------------------------------------------
 # networks (networks/encoder.py, networks/decoder.py, networks/transducer.py) — torch-CPU composite
 # ----------------------------------------------------------------------------------------------------
-def _packed_lstm(rnn: nn.LSTM, x: torch.Tensor, lens: Sequence[int]) -> torch.Tensor:
+def _packed_lstm(rnn: nn.Module, x: torch.Tensor, lens: Sequence[int]) -> torch.Tensor:
     """encoder.py:93-102 / decoder.py:105-120: packed-sequence LSTM, zero outputs on padded frames."""
     total = x.size(1)
     packed = nn.utils.rnn.pack_padded_sequence(x, torch.as_tensor(list(lens), device="cpu"), batch_first=True,
@@ -176,9 +176,9 @@ class OracleJointNet(nn.Module):
         def __init__(self, input_size, hidden_size, output_size, num_layers, rnn_type="lstm", dropout=0.2,
                      bidirectional=True):
             super().__init__()
-            assert rnn_type.lower() == "lstm"
-            self.rnn = nn.LSTM(input_size, hidden_size, num_layers, bias=True, batch_first=True,
-                               dropout=dropout if num_layers > 1 else 0.0, bidirectional=bidirectional)
+            cell = {"lstm": nn.LSTM, "gru": nn.GRU, "rnn": nn.RNN}[rnn_type.lower()]  # encoder.py:48-52
+            self.rnn = cell(input_size, hidden_size, num_layers, bias=True, batch_first=True,
+                            dropout=dropout if num_layers > 1 else 0.0, bidirectional=bidirectional)
             self.out_proj = nn.Linear(hidden_size * (2 if bidirectional else 1), output_size)
 
         def forward(self, x, lens):
@@ -188,10 +188,10 @@ class OracleJointNet(nn.Module):
         def __init__(self, embedding_size, pad_token_id, hidden_size, output_size, num_layers, rnn_type="lstm",
                      dropout=0.2):
             super().__init__()
-            assert rnn_type.lower() == "lstm"
+            cell = {"lstm": nn.LSTM, "gru": nn.GRU, "rnn": nn.RNN}[rnn_type.lower()]  # decoder.py:51-55
             self.embedding = nn.Embedding(embedding_size, hidden_size, padding_idx=pad_token_id)
-            self.rnn = nn.LSTM(hidden_size, hidden_size, num_layers, bias=True, batch_first=True,
-                               dropout=dropout if num_layers > 1 else 0.0, bidirectional=False)
+            self.rnn = cell(hidden_size, hidden_size, num_layers, bias=True, batch_first=True,
+                            dropout=dropout if num_layers > 1 else 0.0, bidirectional=False)
             self.out_proj = nn.Linear(hidden_size, output_size)
 
         def forward(self, tokens, lens):

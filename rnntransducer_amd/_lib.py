@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librnnt_hip.so")
 
 GEMM_GELU_A, GEMM_GELU_B, GEMM_ACCUM, GEMM_MUL_DGELU = 1, 2, 4, 8
+CELL_LSTM, CELL_GRU, CELL_RNN_TANH, CELL_RNN_RELU = 0, 1, 2, 3
 
 c_f32p = C.c_void_p
 c_i64 = C.c_int64
@@ -27,17 +28,17 @@ class GemmDesc(C.Structure):
 
 
 class LstmDesc(C.Structure):
-    _fields_ = [("T", c_i32), ("B", c_i32), ("I", c_i32), ("H", c_i32), ("D", c_i32), ("lens", C.c_void_p),
+    _fields_ = [("T", c_i32), ("B", c_i32), ("I", c_i32), ("H", c_i32), ("D", c_i32), ("cell", c_i32), ("lens", C.c_void_p),
                 ("x", C.c_void_p), ("x_st", c_i64), ("x_sb", c_i64), ("w_ih", C.c_void_p * 2),
                 ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2), ("y", C.c_void_p),
                 ("y_drop", C.c_void_p), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
-                ("gates", C.c_void_p), ("cst", C.c_void_p), ("workspace", C.c_void_p),
+                ("gates", C.c_void_p), ("cst", C.c_void_p), ("aux", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t)]
 
 
 class LstmBwdDesc(C.Structure):
     _fields_ = [("f", LstmDesc), ("dy", C.c_void_p), ("dx", C.c_void_p), ("dw_ih", C.c_void_p * 2),
-                ("dw_hh", C.c_void_p * 2), ("db", C.c_void_p * 2)]
+                ("dw_hh", C.c_void_p * 2), ("db", C.c_void_p * 2), ("db_hh", C.c_void_p * 2)]
 
 
 # every symbol include/rnnt_hip.h declares: (name, restype, argtypes)

@@ -57,6 +57,9 @@ struct LstmK {
   const float* dy; // bwd: (T,B,D,H)
   int G, Bg, Kp;   // v2: batch groups per direction, rows per group, K padded to a multiple of 64
   unsigned long long* dbg;  // diagnostic builds only (RNNT_LSTM_DBG): per-workgroup phase cycle sums, else nullptr
+  int cell;        // RNNT_CELL_* (v2 kernels; v1 is LSTM only)
+  const float* b_hh[2];  // GRU: the hidden-side bias of the n gate stays inside r * (W_hn h + b_hn)
+  float* aux;      // GRU backward: hidden-side gate gradients (T,B,D,4H) for dW_hh / db_hh
   unsigned* xcc;   // v2: [D*G][NC] XCC id + 1 of every member, published once at kernel start (zeroed per launch)
   int allow_local; // v2: permit the L2-local exchange when a group is verified to sit on one XCD
 };
@@ -562,8 +565,11 @@ __host__ __device__ constexpr int stage_floats() {
 }
 
 // dynamic LDS: WA[4][Ls/4][64] f32x4 | hs[4][stage_floats] | part[4][BQ][64] f32x4 | abort
-template <int HS, int BQ>
+// CELL: 0 LSTM (slots i,f,g,o), 1 GRU (slots r,z,n,-), 2 Elman RNN (slot 0; tanh or relu by p.cell).  Every cell type keeps
+// the 4-slots-per-unit layout of the gate buffer and of the MFMA row-quads; unused slots carry zero weights.
+template <int HS, int BQ, int CELL>
 __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
+  constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
   constexpr int KS = 16 / HS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
@@ -586,10 +592,12 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
       const int i = ln & 3, blk = ln >> 2, rq = blk % HS, ks = blk / HS;
       const int k = w * Kw + ks * Ls + 4 * s4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const float* row = W + (long)(i * H + j0 + rq) * H;
+      if (i < NGATE) {
+        const float* row = W + (long)(i * H + j0 + rq) * H;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (k + e < H) v[e] = row[k + e];
+        for (int e = 0; e < 4; ++e)
+          if (k + e < H) v[e] = row[k + e];
+      }
       WA[idx] = v;
     }
     if (tid == 0) *abort_lds = 0;
@@ -609,7 +617,8 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
   const int ob = b0 + brow, oj = j0 + ounit;
   const bool valid = owner && brow < p.Bg && ob < B;
   const int olen = valid ? p.lens[ob] : 0;
-  float c_state = 0.f;
+  float c_state = 0.f;  // LSTM: cell state; GRU / RNN: previous hidden state of this cell
+  const float bhn = (CELL == 1 && owner) ? p.b_hh[d][2 * H + oj] : 0.f;
   const int myks = (lane >> 2) / HS;
   // per-step addresses advance by constant strides: keep running offsets instead of 64-bit multiplies in the loop
   const int t_first = (d == 0) ? 0 : T - 1;
@@ -647,18 +656,33 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
     f32x4 gact = {0.f, 0.f, 0.f, 0.f}, h4 = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
     bool quad_lead = false;
     if (owner) {
-      f32x4 g4 = xp;
+      f32x4 rec = {0.f, 0.f, 0.f, 0.f};  // h_{t-1} . W_hh^T for this cell's slots
 #pragma unroll
       for (int w = 0; w < 4; ++w)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) g4 += part[(w * BQ + obq) * 64 + ks * 4 * HS + ol];
+        for (int ks = 0; ks < KS; ++ks) rec += part[(w * BQ + obq) * 64 + ks * 4 * HS + ol];
       const bool active = valid && t < olen;
       float hval = 0.f;
       if (active) {
-        const float ig = sigmoid_hw(g4[0]), fg = sigmoid_hw(g4[1]), gg = tanh_hw(g4[2]), og = sigmoid_hw(g4[3]);
-        c_state = fg * c_state + ig * gg;
-        hval = og * tanh_hw(c_state);
-        gact = (f32x4){ig, fg, gg, og};
+        if constexpr (CELL == 0) {
+          const f32x4 g4 = xp + rec;
+          const float ig = sigmoid_hw(g4[0]), fg = sigmoid_hw(g4[1]), gg = tanh_hw(g4[2]), og = sigmoid_hw(g4[3]);
+          c_state = fg * c_state + ig * gg;
+          hval = og * tanh_hw(c_state);
+          gact = (f32x4){ig, fg, gg, og};
+        } else if constexpr (CELL == 1) {
+          const float rg = sigmoid_hw(xp[0] + rec[0]), zg = sigmoid_hw(xp[1] + rec[1]);
+          const float hn = rec[2] + bhn;
+          const float ng = tanh_hw(xp[2] + rg * hn);
+          hval = (1.f - zg) * ng + zg * c_state;
+          c_state = hval;
+          gact = (f32x4){rg, zg, ng, hn};
+        } else {
+          const float pre = xp[0] + rec[0];
+          hval = (p.cell == RNNT_CELL_RNN_RELU) ? fmaxf(pre, 0.f) : tanh_hw(pre);
+          c_state = hval;
+          gact = (f32x4){hval, 0.f, 0.f, 0.f};
+        }
       } else {
         c_state = 0.f;
       }
@@ -676,7 +700,7 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
     if (valid) {
       *reinterpret_cast<f32x4*>(p.gates + g_off) = gact;
       if (quad_lead) {
-        *reinterpret_cast<f32x4*>(p.cst + c_off) = c4;
+        if constexpr (CELL == 0) *reinterpret_cast<f32x4*>(p.cst + c_off) = c4;
         const long yo = y_off;
         *reinterpret_cast<f32x4*>(p.y + yo) = h4;
         if (p.ydrop) {
@@ -707,8 +731,9 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
 }
 
 // dynamic LDS: WA[4][Ls/4][64] f32x4 | hs[4][stage_floats] | part[4][BQ][64] f32x4 | abort
-template <int HS, int BQ>
+template <int HS, int BQ, int CELL>
 __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
+  constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
   constexpr int UQ = HS / 4, KS = 16 / UQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
@@ -734,7 +759,7 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (jp < H) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = W[(long)(e * H + jp) * H + col];
+        for (int e = 0; e < NGATE; ++e) v[e] = W[(long)(e * H + jp) * H + col];
       }
       WA[idx] = v;
     }
@@ -777,8 +802,12 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
     const bool active = valid && t < olen;
     if (active) {
       gt = *reinterpret_cast<const f32x4*>(p.gates + g_off);
-      c_t = p.cst[c_off];
-      if (tprev >= 0 && tprev < T) c_p = p.cst[c_off + c_step];  // the backward walks towards the forward's t_prev
+      if constexpr (CELL == 0) {
+        c_t = p.cst[c_off];
+        if (tprev >= 0 && tprev < T) c_p = p.cst[c_off + c_step];  // the backward walks towards the forward's t_prev
+      } else if constexpr (CELL == 1) {
+        if (tprev >= 0 && tprev < T) c_p = p.y[y_off + y_step];    // GRU: h_{t_prev} of this cell (0 at the sequence start)
+      }
       const long yo = y_off;
       dyv = p.dy[yo];
       if (p.ydrop) dyv = (hash_u32(p.seed, (unsigned long long)yo) >= p.drop_thresh) ? dyv * p.keep_scale : 0.f;
@@ -798,7 +827,7 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
 #pragma unroll
     for (int bq = 0; bq < BQ; ++bq) *reinterpret_cast<f32x4*>(&part[((wave * BQ + bq) * 64 + lane) * 4]) = acc[bq];
     __syncthreads();
-    f32x4 dg4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dg4 = {0.f, 0.f, 0.f, 0.f}, dgh4 = {0.f, 0.f, 0.f, 0.f};
     if (owner) {
       float dh = dyv;
 #pragma unroll
@@ -806,23 +835,43 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) dh += part[((w * BQ + obq) * 64 + 4 * (ks * UQ + ouq) + ojb) * 4 + oi];
       if (active) {
-        const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
-        const float tc = tanh_hw(c_t);
-        const float dc = dh * og * (1.f - tc * tc) + dc_carry;
-        dg4[0] = dc * gg * ig * (1.f - ig);
-        dg4[1] = dc * c_p * fg * (1.f - fg);
-        dg4[2] = dc * ig * (1.f - gg * gg);
-        dg4[3] = dh * tc * og * (1.f - og);
-        dc_carry = dc * fg;
+        if constexpr (CELL == 0) {
+          const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
+          const float tc = tanh_hw(c_t);
+          const float dc = dh * og * (1.f - tc * tc) + dc_carry;
+          dg4[0] = dc * gg * ig * (1.f - ig);
+          dg4[1] = dc * c_p * fg * (1.f - fg);
+          dg4[2] = dc * ig * (1.f - gg * gg);
+          dg4[3] = dh * tc * og * (1.f - og);
+          dc_carry = dc * fg;
+          dgh4 = dg4;
+        } else if constexpr (CELL == 1) {
+          const float rg = gt[0], zg = gt[1], ng = gt[2], hn = gt[3];
+          dh += dc_carry;                       // direct path dh_t -> dh_{t_prev} through z
+          const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+          const float dz_pre = dh * (c_p - ng) * zg * (1.f - zg);
+          const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+          dg4 = (f32x4){dr_pre, dz_pre, dn_pre, 0.f};        // input side: dX, dW_ih, db_ih
+          dgh4 = (f32x4){dr_pre, dz_pre, dn_pre * rg, 0.f};  // hidden side: W_hh^T product, dW_hh, db_hh
+          dc_carry = dh * zg;
+        } else {
+          const float hv = gt[0];
+          const float dpre = (p.cell == RNNT_CELL_RNN_RELU) ? (hv > 0.f ? dh : 0.f) : dh * (1.f - hv * hv);
+          dg4 = (f32x4){dpre, 0.f, 0.f, 0.f};
+          dgh4 = dg4;
+        }
       } else {
         dc_carry = 0.f;
       }
-      exchange_store<LOCAL>(__builtin_bit_cast(i32x4, dg4), gx_rsrc[s & 1], gx_off);
+      exchange_store<LOCAL>(__builtin_bit_cast(i32x4, dgh4), gx_rsrc[s & 1], gx_off);
     }
     DBG_STAMP(3);  // LDS reduce + cell math + exchange store issue
     publish_flag2<LOCAL>(flags + wg, (unsigned)(s + 1));
     DBG_STAMP(4);  // drain + barrier + flag
-    if (valid) *reinterpret_cast<f32x4*>(p.gates + g_off) = dg4;  // stash after the flag (off the critical path)
+    if (valid) {  // stash after the flag (off the critical path)
+      *reinterpret_cast<f32x4*>(p.gates + g_off) = dg4;
+      if constexpr (CELL == 1) *reinterpret_cast<f32x4*>(p.aux + g_off) = dgh4;
+    }
     g_off += g_step;
     c_off += c_step;
     y_off += y_step;
@@ -844,8 +893,8 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-// out[(d*4H + 4j+g)*I + k] = w[d][(g*H + j)*I + k]
-__global__ void permute_w_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int H, int I,
+// out[(d*4H + 4j+g)*I + k] = g < ngate ? w[d][(g*H + j)*I + k] : 0      (4 slots per unit whatever the cell type)
+__global__ void permute_w_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int H, int I, int ngate,
                                  float* __restrict__ out) {
   const long per = (long)4 * H * I;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -853,27 +902,33 @@ __global__ void permute_w_kernel(const float* __restrict__ w0, const float* __re
   if (idx >= per) return;
   const int k = (int)(idx % I), r = (int)(idx / I);
   const float* w = d ? w1 : w0;
-  out[d * per + idx] = w[(long)((r & 3) * H + (r >> 2)) * I + k];
+  out[d * per + idx] = (r & 3) < ngate ? w[(long)((r & 3) * H + (r >> 2)) * I + k] : 0.f;
 }
 // inverse for gradients: dw[d][(g*H + j)*I + k] = in[(d*4H + 4j+g)*I + k]
-__global__ void unpermute_w_kernel(const float* __restrict__ in, int H, int I, long in_dir_stride, float* __restrict__ o0,
-                                   float* __restrict__ o1) {
+__global__ void unpermute_w_kernel(const float* __restrict__ in, int H, int I, long in_dir_stride, int ngate,
+                                   float* __restrict__ o0, float* __restrict__ o1) {
   const long per = (long)4 * H * I;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const int d = blockIdx.y;
   if (idx >= per) return;
   const int k = (int)(idx % I), r = (int)(idx / I);
   float* o = d ? o1 : o0;
-  o[(long)((r & 3) * H + (r >> 2)) * I + k] = in[d * in_dir_stride + idx];
+  if ((r & 3) < ngate) o[(long)((r & 3) * H + (r >> 2)) * I + k] = in[d * in_dir_stride + idx];
 }
+// bias folded into the hoisted input projection: b_ih + b_hh per slot; GRU keeps b_hn out (it sits inside r * (.))
 __global__ void permute_bias_kernel(const float* __restrict__ bi0, const float* __restrict__ bh0,
-                                    const float* __restrict__ bi1, const float* __restrict__ bh1, int H,
-                                    float* __restrict__ out) {
+                                    const float* __restrict__ bi1, const float* __restrict__ bh1, int H, int ngate,
+                                    int gru, float* __restrict__ out) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int d = blockIdx.y;
   if (idx >= 4 * H) return;
-  const int src = (idx & 3) * H + (idx >> 2);
-  out[d * 4 * H + idx] = d ? bi1[src] + bh1[src] : bi0[src] + bh0[src];
+  const int g = idx & 3, src = g * H + (idx >> 2);
+  float v = 0.f;
+  if (g < ngate) {
+    const float bi = d ? bi1[src] : bi0[src], bh = d ? bh1[src] : bh0[src];
+    v = (gru && g == 2) ? bi : bi + bh;
+  }
+  out[d * 4 * H + idx] = v;
 }
 
 // two-stage deterministic column sum.  stage 1: grid (ceil(N/64), RC): block (64 columns x 4 row lanes) sums its
@@ -1112,21 +1167,27 @@ int launch_persistent2(K kernel, const LstmK& k, const Plan2& pl, size_t lds, hi
   return RNNT_OK;
 }
 
-#define DISPATCH_HS_BQ(KERNEL, pl, ...)                                                     \
+#define DISPATCH_HS_BQ_C(KERNEL, C, pl, ...)                                                \
   do {                                                                                      \
     const int key_ = (pl).HS * 10 + (pl).BQ;                                                \
     switch (key_) {                                                                         \
-      case 41: rc = launch_persistent2(KERNEL<4, 1>, __VA_ARGS__); break;                   \
-      case 42: rc = launch_persistent2(KERNEL<4, 2>, __VA_ARGS__); break;                   \
-      case 44: rc = launch_persistent2(KERNEL<4, 4>, __VA_ARGS__); break;                   \
-      case 81: rc = launch_persistent2(KERNEL<8, 1>, __VA_ARGS__); break;                   \
-      case 82: rc = launch_persistent2(KERNEL<8, 2>, __VA_ARGS__); break;                   \
-      case 84: rc = launch_persistent2(KERNEL<8, 4>, __VA_ARGS__); break;                   \
-      case 161: rc = launch_persistent2(KERNEL<16, 1>, __VA_ARGS__); break;                 \
-      case 162: rc = launch_persistent2(KERNEL<16, 2>, __VA_ARGS__); break;                 \
-      case 164: rc = launch_persistent2(KERNEL<16, 4>, __VA_ARGS__); break;                 \
+      case 41: rc = launch_persistent2(KERNEL<4, 1, C>, __VA_ARGS__); break;                \
+      case 42: rc = launch_persistent2(KERNEL<4, 2, C>, __VA_ARGS__); break;                \
+      case 44: rc = launch_persistent2(KERNEL<4, 4, C>, __VA_ARGS__); break;                \
+      case 81: rc = launch_persistent2(KERNEL<8, 1, C>, __VA_ARGS__); break;                \
+      case 82: rc = launch_persistent2(KERNEL<8, 2, C>, __VA_ARGS__); break;                \
+      case 84: rc = launch_persistent2(KERNEL<8, 4, C>, __VA_ARGS__); break;                \
+      case 161: rc = launch_persistent2(KERNEL<16, 1, C>, __VA_ARGS__); break;              \
+      case 162: rc = launch_persistent2(KERNEL<16, 2, C>, __VA_ARGS__); break;              \
+      case 164: rc = launch_persistent2(KERNEL<16, 4, C>, __VA_ARGS__); break;              \
       default: set_error("lstm: no v2 kernel for HS=%d BQ=%d", (pl).HS, (pl).BQ); rc = RNNT_ERR_UNSUPPORTED; \
     }                                                                                       \
+  } while (0)
+#define DISPATCH_HS_BQ(KERNEL, cell, pl, ...)                                               \
+  do {                                                                                      \
+    if ((cell) == RNNT_CELL_LSTM) DISPATCH_HS_BQ_C(KERNEL, 0, pl, __VA_ARGS__);             \
+    else if ((cell) == RNNT_CELL_GRU) DISPATCH_HS_BQ_C(KERNEL, 1, pl, __VA_ARGS__);         \
+    else DISPATCH_HS_BQ_C(KERNEL, 2, pl, __VA_ARGS__);                                      \
   } while (0)
 
 int check_desc(const rnnt_lstm_desc* d, Plan* pl, LstmWs* w) {
@@ -1139,7 +1200,8 @@ int check_desc(const rnnt_lstm_desc* d, Plan* pl, LstmWs* w) {
               d->B, d->H, d->D, cus);
     return RNNT_ERR_UNSUPPORTED;
   }
-  RNNT_CHECK_ARG(d->lens && d->x && d->y && d->gates && d->cst, "lstm: null tensor");
+  RNNT_CHECK_ARG(d->cell >= RNNT_CELL_LSTM && d->cell <= RNNT_CELL_RNN_RELU, "lstm: unknown cell type %d", d->cell);
+  RNNT_CHECK_ARG(d->lens && d->x && d->y && d->gates && (d->cst || d->cell != RNNT_CELL_LSTM), "lstm: null tensor");
   for (int k = 0; k < d->D; ++k)
     RNNT_CHECK_ARG(d->w_ih[k] && d->w_hh[k] && d->b_ih[k] && d->b_hh[k], "lstm: null weight (direction %d)", k);
   RNNT_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "lstm: dropout_p must be in [0,1)");
@@ -1148,7 +1210,8 @@ int check_desc(const rnnt_lstm_desc* d, Plan* pl, LstmWs* w) {
   RNNT_CHECK_ARG(d->workspace && d->workspace_bytes >= w->total, "lstm: workspace too small (%zu < %zu)",
                  d->workspace_bytes, w->total);
   RNNT_CHECK_ARG((reinterpret_cast<uintptr_t>(d->gates) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
-                     (reinterpret_cast<uintptr_t>(d->cst) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->workspace) & 255) == 0,
+                     (reinterpret_cast<uintptr_t>(d->cst) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->aux) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(d->workspace) & 255) == 0,
                  "lstm: gates/y/cst must be 16-byte aligned, workspace 256-byte aligned");
   return RNNT_OK;
 }
@@ -1164,6 +1227,9 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->w_hh[0] = d->w_hh[0]; k->w_hh[1] = d->D > 1 ? d->w_hh[1] : d->w_hh[0];
   k->hx = w.hx; k->status = w.flags; k->flags = w.flags + 16;
   k->dy = nullptr;
+  k->cell = d->cell;
+  k->b_hh[0] = d->b_hh[0]; k->b_hh[1] = d->D > 1 ? d->b_hh[1] : d->b_hh[0];
+  k->aux = d->aux;
   k->G = 1; k->Bg = d->B; k->Kp = d->H;
   k->dbg = getenv("RNNT_LSTM_DBG") ? w.dbg : nullptr;
   k->xcc = w.flags + 16 + w.nflags;
@@ -1206,14 +1272,16 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   if (int rc = check_desc(d, &pl, &w)) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int H = d->H, D = d->D, I = d->I;
+  const int ngate = d->cell == RNNT_CELL_LSTM ? 4 : (d->cell == RNNT_CELL_GRU ? 3 : 1);
   // 1. gate-adjacent copy of W_ih (both directions stacked) and of b_ih + b_hh
   {
     const long per = (long)4 * H * I;
     hipLaunchKernelGGL(permute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, d->w_ih[0],
-                       D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, w.wp);
+                       D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, ngate, w.wp);
     RNNT_CHECK_LAUNCH();
     hipLaunchKernelGGL(permute_bias_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, d->b_ih[0], d->b_hh[0],
-                       D > 1 ? d->b_ih[1] : d->b_ih[0], D > 1 ? d->b_hh[1] : d->b_hh[0], H, w.bp);
+                       D > 1 ? d->b_ih[1] : d->b_ih[0], D > 1 ? d->b_hh[1] : d->b_hh[0], H, ngate,
+                       d->cell == RNNT_CELL_GRU ? 1 : 0, w.bp);
     RNNT_CHECK_LAUNCH();
   }
   // 2. hoisted input projection for all timesteps: gates[(t,b)][d*4H + 4j+g] = x(t,b,:) . W_ih'[.] + bias'
@@ -1235,9 +1303,12 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   Plan2 p2;
   if (make_plan2(d->B, d->H, d->D, device_cus(), &p2)) {
     k.NC = p2.NC; k.Hs = p2.HS; k.G = p2.G; k.Bg = p2.Bg; k.Kp = p2.Kp;
-    DISPATCH_HS_BQ(lstm_fwd2_kernel, p2, k, p2, p2.lds_fwd, s, "lstm_fwd2");
-  } else {
+    DISPATCH_HS_BQ(lstm_fwd2_kernel, d->cell, p2, k, p2, p2.lds_fwd, s, "lstm_fwd2");
+  } else if (d->cell == RNNT_CELL_LSTM) {
     DISPATCH_MT_NT(lstm_fwd_kernel, pl, k, pl, pl.lds_fwd, s, "lstm_fwd");
+  } else {
+    set_error("rnn: GRU / Elman cells need the grouped decomposition (B/G <= 16 rows per group); B=%d H=%d does not fit", d->B, d->H);
+    rc = RNNT_ERR_UNSUPPORTED;
   }
   return rc;
 }
@@ -1250,6 +1321,11 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   if (int rc = check_desc(d, &pl, &w)) return rc;
   RNNT_CHECK_ARG(bd->dy, "lstm_bwd: null dy");
   const int T = d->T, B = d->B, H = d->H, D = d->D, I = d->I;
+  const bool gru = d->cell == RNNT_CELL_GRU;
+  const int ngate = d->cell == RNNT_CELL_LSTM ? 4 : (gru ? 3 : 1);
+  RNNT_CHECK_ARG(!gru || d->aux, "lstm_bwd: GRU needs the aux buffer (T,B,D*4H)");
+  for (int k = 0; k < D; ++k) RNNT_CHECK_ARG(!gru || bd->db_hh[k], "lstm_bwd: GRU needs db_hh");
+  const float* ghid = gru ? d->aux : d->gates;  // hidden-side gate gradients (== input side except for GRU's n gate)
   RNNT_CHECK_ARG(d->x_sb == I && d->x_st == (int64_t)B * I, "lstm_bwd: x must be time-major contiguous (T,B,I)");
   for (int k = 0; k < D; ++k) RNNT_CHECK_ARG(bd->dw_ih[k] && bd->dw_hh[k] && bd->db[k], "lstm_bwd: null gradient output");
   hipStream_t s = (hipStream_t)stream;
@@ -1264,9 +1340,12 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   Plan2 p2;
   if (make_plan2(d->B, d->H, d->D, device_cus(), &p2)) {
     k.NC = p2.NC; k.Hs = p2.HS; k.G = p2.G; k.Bg = p2.Bg; k.Kp = p2.Kp;
-    DISPATCH_HS_BQ(lstm_bwd2_kernel, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
-  } else {
+    DISPATCH_HS_BQ(lstm_bwd2_kernel, d->cell, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
+  } else if (d->cell == RNNT_CELL_LSTM) {
     DISPATCH_MT_NT(lstm_bwd_kernel, pl, k, pl, pl.lds_bwd, s, "lstm_bwd");
+  } else {
+    set_error("rnn: GRU / Elman cells need the grouped decomposition; B=%d H=%d does not fit", d->B, d->H);
+    rc = RNNT_ERR_UNSUPPORTED;
   }
   if (rc) return rc;
 
@@ -1275,7 +1354,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   if (bd->dx) {
     const long per = (long)4 * H * I;
     hipLaunchKernelGGL(permute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, d->w_ih[0],
-                       D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, w.wp);
+                       D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, ngate, w.wp);
     RNNT_CHECK_LAUNCH();
     rnnt_gemm_desc g = {};
     g.M = M; g.N = I; g.K = N4;
@@ -1294,7 +1373,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     g.workspace = w.scratch; g.workspace_bytes = w.scratch_bytes;
     if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
     const long per = (long)4 * H * I;
-    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per,
+    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per, ngate,
                        bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0]);
     RNNT_CHECK_LAUNCH();
   }
@@ -1304,7 +1383,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     g.M = 4 * H; g.N = H; g.K = (int64_t)(T - 1) * B;
     const int64_t shift_g = dir == 0 ? (int64_t)B * N4 : 0;           // dG rows t = 1..T-1 | 0..T-2
     const int64_t shift_y = dir == 0 ? 0 : (int64_t)B * D * H;        // y  rows t = 0..T-2 | 1..T-1
-    g.A = d->gates + shift_g + (int64_t)dir * 4 * H; g.a_mc = 1; g.a_sk = N4; g.a_div = 1;
+    g.A = ghid + shift_g + (int64_t)dir * 4 * H; g.a_mc = 1; g.a_sk = N4; g.a_div = 1;
     g.B = d->y + shift_y + (int64_t)dir * H; g.b_sn = 1; g.b_sk = (int64_t)D * H;
     g.C = w.dwhh + (int64_t)dir * 4 * H * H; g.c_div = 1; g.c_so = H; g.c_si = 0;
     g.workspace = w.scratch; g.workspace_bytes = w.scratch_bytes;
@@ -1316,16 +1395,22 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   }
   {
     const long per = (long)4 * H * H;
-    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.dwhh, H, H, per,
+    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.dwhh, H, H, per, ngate,
                        bd->dw_hh[0], D > 1 ? bd->dw_hh[1] : bd->dw_hh[0]);
     RNNT_CHECK_LAUNCH();
   }
   // 5. bias gradient = column sums of dG, un-permuted
   {
     if ((rc = launch_colsum(d->gates, (long)M, (long)N4, (long)N4, w.bp, w.scratch, w.scratch_bytes, s))) return rc;
-    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, w.bp, H, 1, (long)4 * H,
+    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, w.bp, H, 1, (long)4 * H, ngate,
                        bd->db[0], D > 1 ? bd->db[1] : bd->db[0]);
     RNNT_CHECK_LAUNCH();
+    if (gru) {  // b_hh sees the hidden-side gradients (n gate scaled by r)
+      if ((rc = launch_colsum(ghid, (long)M, (long)N4, (long)N4, w.bp, w.scratch, w.scratch_bytes, s))) return rc;
+      hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, w.bp, H, 1, (long)4 * H, ngate,
+                         bd->db_hh[0], D > 1 ? bd->db_hh[1] : bd->db_hh[0]);
+      RNNT_CHECK_LAUNCH();
+    }
   }
   return RNNT_OK;
 }

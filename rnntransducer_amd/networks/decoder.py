@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from ..ops import EmbeddingFn
 from .encoder import HipLinear, lengths_to_device
-from .rnn import HipLSTM
+from .rnn import RNN_CELLS
 
 
 class HipEmbedding(nn.Embedding):
@@ -23,17 +23,17 @@ class HipEmbedding(nn.Embedding):
 
 
 class TextPredNet(nn.Module):
-    supported_rnns = ("lstm",)
+    supported_rnns = RNN_CELLS
 
     def __init__(self, embedding_size: int, pad_token_id: int, hidden_size: int, output_size: int, num_layers: int,
                  rnn_type: str = "lstm", dropout: float = 0.2):
         super().__init__()
         if rnn_type.lower() not in self.supported_rnns:
-            raise NotImplementedError(f"rnn_type={rnn_type!r}: only 'lstm' has a HIP kernel in this version")
+            raise NotImplementedError(f"rnn_type={rnn_type!r}: supported {sorted(self.supported_rnns)}")
         self.hidden_size = hidden_size
         self.embedding = HipEmbedding(embedding_size, hidden_size, padding_idx=pad_token_id)
-        self.rnn = HipLSTM(hidden_size, hidden_size, num_layers, dropout=(dropout if num_layers > 1 else 0.0),
-                           bidirectional=False)
+        self.rnn = self.supported_rnns[rnn_type.lower()](hidden_size, hidden_size, num_layers,
+                                                         dropout=(dropout if num_layers > 1 else 0.0), bidirectional=False)
         self.out_proj = HipLinear(hidden_size, output_size)
 
     def forward_time_major(self, inputs: torch.Tensor, lens_dev: torch.Tensor) -> torch.Tensor:

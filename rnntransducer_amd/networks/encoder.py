@@ -4,7 +4,7 @@ Mirrors the constructor and forward signature of the reference's networks/encode
 argument names, same parameter names `rnn.*`, `out_proj.*`).  What differs is HOW: no sort / pack /
 unpack / unsort and no cuDNN/MIOpen; sequences are masked per row inside the persistent HIP LSTM kernel,
 which gives the same result (zero outputs on padded frames, reverse direction starting at each sequence's
-last frame).  Only rnn_type="lstm" is built in this version (GRU/RNN: SURVEY.md §8 f-1, next).
+last frame).  rnn_type is one of the reference's supported_rnns (lstm | gru | rnn, encoder.py:48-52).
 """
 from typing import Sequence, Union
 
@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..ops import LinearFn
-from .rnn import HipLSTM
+from .rnn import RNN_CELLS
 
 
 def lengths_to_device(lengths: Union[Sequence[int], torch.Tensor], device) -> torch.Tensor:
@@ -30,16 +30,17 @@ class HipLinear(nn.Linear):
 
 
 class AudioTransNet(nn.Module):
-    supported_rnns = ("lstm",)
+    supported_rnns = RNN_CELLS
 
     def __init__(self, input_size: int, hidden_size: int, output_size: int, num_layers: int, rnn_type: str = "lstm",
                  dropout: float = 0.2, bidirectional: bool = True):
         super().__init__()
         if rnn_type.lower() not in self.supported_rnns:
-            raise NotImplementedError(f"rnn_type={rnn_type!r}: only 'lstm' has a HIP kernel in this version")
+            raise NotImplementedError(f"rnn_type={rnn_type!r}: supported {sorted(self.supported_rnns)}")
         self.hidden_size = hidden_size
-        self.rnn = HipLSTM(input_size, hidden_size, num_layers, dropout=(dropout if num_layers > 1 else 0.0),
-                           bidirectional=bidirectional)
+        self.rnn = self.supported_rnns[rnn_type.lower()](input_size, hidden_size, num_layers,
+                                                         dropout=(dropout if num_layers > 1 else 0.0),
+                                                         bidirectional=bidirectional)
         self.out_proj = HipLinear(2 * hidden_size if bidirectional else hidden_size, output_size)
 
     def forward_time_major(self, inputs: torch.Tensor, lens_dev: torch.Tensor) -> torch.Tensor:

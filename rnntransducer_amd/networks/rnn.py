@@ -1,4 +1,5 @@
-"""HipLSTM: parameter container + forward for the persistent HIP LSTM (no torch.nn.LSTM / MIOpen call).
+"""HipLSTM / HipGRU / HipRNN: parameter containers + forward for the persistent HIP recurrences (no torch.nn.LSTM/GRU/RNN,
+no MIOpen call) — the reference's `supported_rnns = {lstm, gru, rnn}` (networks/encoder.py:48-52, decoder.py:51-55).
 
 Parameter names, shapes, gate order (i,f,g,o) and initialisation order are those of torch.nn.LSTM, which the
 reference instantiates at networks/encoder.py:67-75 and networks/decoder.py:71-79, so reference checkpoints
@@ -13,21 +14,24 @@ from ..ops import LstmStackFn
 
 
 class HipLSTM(nn.Module):
+    GATES, CELL = 4, 0  # i,f,g,o
+
     def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1, dropout: float = 0.0,
                  bidirectional: bool = False):
         super().__init__()
         if hidden_size % 4 != 0:
-            raise ValueError("HipLSTM needs hidden_size % 4 == 0 (each workgroup owns 4-unit slices)")
+            raise ValueError(f"{type(self).__name__} needs hidden_size % 4 == 0 (each workgroup owns 4-unit slices)")
         self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
         self.dropout, self.bidirectional = float(dropout), bool(bidirectional)
         D = 2 if bidirectional else 1
         for layer in range(num_layers):
             in_l = input_size if layer == 0 else hidden_size * D
             for suffix in ("", "_reverse")[:D]:
-                self.register_parameter(f"weight_ih_l{layer}{suffix}", nn.Parameter(torch.empty(4 * hidden_size, in_l)))
-                self.register_parameter(f"weight_hh_l{layer}{suffix}", nn.Parameter(torch.empty(4 * hidden_size, hidden_size)))
-                self.register_parameter(f"bias_ih_l{layer}{suffix}", nn.Parameter(torch.empty(4 * hidden_size)))
-                self.register_parameter(f"bias_hh_l{layer}{suffix}", nn.Parameter(torch.empty(4 * hidden_size)))
+                G = self.GATES
+                self.register_parameter(f"weight_ih_l{layer}{suffix}", nn.Parameter(torch.empty(G * hidden_size, in_l)))
+                self.register_parameter(f"weight_hh_l{layer}{suffix}", nn.Parameter(torch.empty(G * hidden_size, hidden_size)))
+                self.register_parameter(f"bias_ih_l{layer}{suffix}", nn.Parameter(torch.empty(G * hidden_size)))
+                self.register_parameter(f"bias_hh_l{layer}{suffix}", nn.Parameter(torch.empty(G * hidden_size)))
         self.reset_parameters()
         self._step = 0
 
@@ -49,5 +53,24 @@ class HipLSTM(nn.Module):
         p = self.dropout if (self.training and self.num_layers > 1) else 0.0
         self._step += 1
         seed = (torch.initial_seed() * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFFFFFF
-        return LstmStackFn.apply(x_tm, lens, self.hidden_size, self.num_layers, self.bidirectional, p, seed,
+        return LstmStackFn.apply(x_tm, lens, self.hidden_size, self.num_layers, self.bidirectional, p, seed, self.CELL,
                                  *self.flat_weights())
+
+
+class HipGRU(HipLSTM):
+    """torch.nn.GRU parameters / equations (gates r,z,n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)))."""
+    GATES, CELL = 3, 1
+
+
+class HipRNN(HipLSTM):
+    """torch.nn.RNN (Elman) parameters; nonlinearity tanh (the reference's default) or relu."""
+    GATES, CELL = 1, 2
+
+    def __init__(self, *args, nonlinearity: str = "tanh", **kwargs):
+        if nonlinearity not in ("tanh", "relu"):
+            raise ValueError("nonlinearity must be tanh or relu")
+        self.CELL = 2 if nonlinearity == "tanh" else 3
+        super().__init__(*args, **kwargs)
+
+
+RNN_CELLS = {"lstm": HipLSTM, "gru": HipGRU, "rnn": HipRNN}

@@ -156,8 +156,10 @@ def lstm_workspace(T: int, B: int, I: int, H: int, D: int, device) -> torch.Tens
     return torch.empty(n, device=device, dtype=torch.uint8)
 
 
-def _fill_lstm_desc(d: LstmDesc, T, B, I, H, D, lens, x, weights, y, y_drop, p, seed, gates, cst, ws) -> None:
+def _fill_lstm_desc(d: LstmDesc, T, B, I, H, D, lens, x, weights, y, y_drop, p, seed, gates, cst, ws, cell=0, aux=None) -> None:
     d.T, d.B, d.I, d.H, d.D = T, B, I, H, D
+    d.cell = cell
+    d.aux = _addr(aux)
     d.lens = _addr(lens)
     d.x = _addr(x)
     d.x_st, d.x_sb = B * I, I
@@ -175,10 +177,11 @@ def _fill_lstm_desc(d: LstmDesc, T, B, I, H, D, lens, x, weights, y, y_drop, p, 
 
 
 class LstmStackFn(torch.autograd.Function):
-    """x (T,B,I) time-major, lens (B) int32 on device -> y (T,B,D*H); zero rows for t >= lens[b]."""
+    """x (T,B,I) time-major, lens (B) int32 on device -> y (T,B,D*H); zero rows for t >= lens[b].
+    `cell`: 0 LSTM, 1 GRU, 2 tanh-RNN, 3 ReLU-RNN (the reference's supported_rnns, encoder.py:48-52)."""
 
     @staticmethod
-    def forward(ctx, x, lens, hidden, num_layers, bidirectional, dropout_p, seed, *weights):
+    def forward(ctx, x, lens, hidden, num_layers, bidirectional, dropout_p, seed, cell, *weights):
         _need_gpu(x, lens, *weights)
         if lens.dtype != torch.int32:
             raise ValueError(f"lengths must be int32 (dataloader.py:23-24), got {lens.dtype}")
@@ -197,16 +200,16 @@ class LstmStackFn(torch.autograd.Function):
             I = cur.shape[-1]
             wl = weights[4 * D * layer:4 * D * (layer + 1)]
             gates = torch.empty(T, B, D * 4 * H, device=dev, dtype=torch.float32)
-            cst = torch.empty(D * T * B * H, device=dev, dtype=torch.float32)
+            cst = torch.empty(D * T * B * H, device=dev, dtype=torch.float32) if cell == 0 else None
             y = torch.empty(T, B, D * H, device=dev, dtype=torch.float32)
             p = dropout_p if layer < num_layers - 1 else 0.0
             y_drop = torch.empty_like(y) if p > 0 else None
             d = LstmDesc()
-            _fill_lstm_desc(d, T, B, I, H, D, lens, cur, wl, y, y_drop, p, seed + layer, gates, cst, ws)
+            _fill_lstm_desc(d, T, B, I, H, D, lens, cur, wl, y, y_drop, p, seed + layer, gates, cst, ws, cell)
             check(_lib.lib().rnnt_hip_lstm_fwd(C.byref(d), _stream()), "rnnt_hip_lstm_fwd")
             saved.append((cur, y, gates, cst, p))
             cur = y_drop if p > 0 else y
-        ctx.meta = (T, B, H, D, num_layers, seed)
+        ctx.meta = (T, B, H, D, num_layers, seed, cell)
         ctx.lens = lens
         ctx.ws = ws
         ctx.saved = saved
@@ -216,7 +219,7 @@ class LstmStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        T, B, H, D, L, seed = ctx.meta
+        T, B, H, D, L, seed, cell = ctx.meta
         dy = _f32c(dy, "dy")
         weights = ctx.weights
         grads: List[Optional[torch.Tensor]] = [None] * len(weights)
@@ -226,8 +229,9 @@ class LstmStackFn(torch.autograd.Function):
             I = x_l.shape[-1]
             wl = weights[4 * D * layer:4 * D * (layer + 1)]
             bd = LstmBwdDesc()
+            aux = torch.empty_like(gates) if cell == 1 else None
             _fill_lstm_desc(bd.f, T, B, I, H, D, ctx.lens, x_l, wl, y_l, y_l if p > 0 else None, p, seed + layer, gates,
-                            cst, ctx.ws)
+                            cst, ctx.ws, cell, aux)
             bd.dy = _addr(dy)
             need_dx = layer > 0 or ctx.x_needs_grad
             dx = torch.empty(T, B, I, device=dy.device, dtype=torch.float32) if need_dx else None
@@ -236,13 +240,15 @@ class LstmStackFn(torch.autograd.Function):
                 dw_ih = torch.empty_like(wl[4 * k])
                 dw_hh = torch.empty_like(wl[4 * k + 1])
                 db = torch.empty_like(wl[4 * k + 2])
+                db_hh = torch.empty_like(db) if cell == 1 else db  # GRU: b_hn sits inside r * (.), its gradient differs
                 bd.dw_ih[k], bd.dw_hh[k], bd.db[k] = _addr(dw_ih), _addr(dw_hh), _addr(db)
+                bd.db_hh[k] = _addr(db_hh) if cell == 1 else None
                 base = 4 * D * layer + 4 * k
-                grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dw_ih, dw_hh, db, db
+                grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dw_ih, dw_hh, db, db_hh
             check(_lib.lib().rnnt_hip_lstm_bwd(C.byref(bd), _stream()), "rnnt_hip_lstm_bwd")
             dy = dx
         ctx.saved = None  # release the stash
-        return (dx if ctx.x_needs_grad else None, None, None, None, None, None, None, *grads)
+        return (dx if ctx.x_needs_grad else None, None, None, None, None, None, None, None, *grads)
 
 
 def lstm_check(ws: torch.Tensor) -> None:

@@ -79,6 +79,20 @@ if __name__ == "__main__":
         dict(embedding_size=10, pad_token_id=0, hidden_size=16, output_size=8, num_layers=2, rnn_type="lstm",
              dropout=0.0),
         10, [12, 9, 5], [4, 2, 3], seed=23)
+    # G3: the cell mix of the reference's SHIPPED config.json (bidirectional GRU encoder, LSTM prediction net), scaled down
+    run("g3_gru",
+        dict(input_size=12, hidden_size=16, output_size=8, num_layers=2, rnn_type="gru", dropout=0.0,
+             bidirectional=True),
+        dict(embedding_size=10, pad_token_id=0, hidden_size=16, output_size=8, num_layers=2, rnn_type="lstm",
+             dropout=0.0),
+        10, [11, 6, 9], [3, 4, 1], seed=41)
+    # G3r: Elman-RNN encoder + GRU prediction net
+    run("g3_rnn",
+        dict(input_size=12, hidden_size=16, output_size=8, num_layers=2, rnn_type="rnn", dropout=0.0,
+             bidirectional=True),
+        dict(embedding_size=10, pad_token_id=0, hidden_size=16, output_size=8, num_layers=1, rnn_type="gru",
+             dropout=0.0),
+        10, [8, 10, 4], [2, 5, 3], seed=43)
     # G2u: uni-directional encoder variant
     run("g2_uni",
         dict(input_size=12, hidden_size=16, output_size=8, num_layers=2, rnn_type="lstm", dropout=0.0,

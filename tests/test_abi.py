@@ -54,7 +54,7 @@ def test_module_surface_mirrors_reference_and_fails_loudly_on_cpu():
         m(torch.zeros(2, 5, 80), [5, 4], torch.zeros(2, 3, dtype=torch.long), [3, 2])
     with pytest.raises(NotImplementedError):
         RNNTransducer(dict(embedding_size=72, hidden_size=128, output_size=128, num_layers=1),
-                      dict(input_size=80, hidden_size=128, output_size=128, num_layers=1, rnn_type="gru"), dict(num_classes=72), args)
+                      dict(input_size=80, hidden_size=128, output_size=128, num_layers=1, rnn_type="transformer"), dict(num_classes=72), args)
 
 
 def test_product_never_imports_the_oracle():

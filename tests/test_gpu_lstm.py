@@ -150,3 +150,47 @@ def test_xcd_local_exchange_is_bitwise_identical_to_write_through(monkeypatch):
         assert torch.equal(a, b)
     assert (results[0][0].transpose(0, 1).double().cpu() - ref_out).abs().max().item() < FWD_ATOL
     assert (results[0][1].transpose(0, 1).double().cpu() - ref_dx).abs().max().item() < GRAD_RTOL * max(ref_dx.abs().max().item(), 1e-3) + 1e-6
+
+
+@pytest.mark.parametrize("cell", ["gru", "rnn_tanh", "rnn_relu"])
+@pytest.mark.parametrize("B,T,I,H,L,bi", [(1, 1, 4, 4, 1, False), (3, 7, 5, 8, 2, True), (5, 20, 80, 16, 2, True), (17, 9, 8, 32, 1, True),
+                                          (32, 11, 16, 512, 1, True), (4, 14, 24, 640, 1, True)])
+def test_gru_and_elman_cells_fwd_bwd(cell, B, T, I, H, L, bi):
+    """the reference's other supported_rnns (encoder.py:48-52) on the same persistent kernels, against
+    torch.nn.GRU / torch.nn.RNN on the CPU in float64 over a PackedSequence."""
+    from rnntransducer_amd.networks.rnn import HipGRU, HipRNN
+    torch.manual_seed(B * 100 + T + H)
+    if cell == "gru":
+        ref = nn.GRU(I, H, L, batch_first=True, bidirectional=bi).double()
+        hip = HipGRU(I, H, L, dropout=0.0, bidirectional=bi)
+    else:
+        nl = cell.split("_")[1]
+        ref = nn.RNN(I, H, L, nonlinearity=nl, batch_first=True, bidirectional=bi).double()
+        hip = HipRNN(I, H, L, dropout=0.0, bidirectional=bi, nonlinearity=nl)
+    assert list(ref.state_dict()) == list(hip.state_dict())
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hip = hip.cuda()
+    g = torch.Generator().manual_seed(1)
+    lens = [T] + torch.randint(1, T + 1, (B - 1,), generator=g).tolist()
+    x = torch.randn(B, T, I, generator=g)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    D = 2 if bi else 1
+    dy = torch.randn(B, T, D * H, generator=g)
+    ref_out, ref_dx = _oracle(x, lens, ref, dy)
+    x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
+    y = hip(x_tm, torch.tensor(lens, dtype=torch.int32, device="cuda"))
+    y.backward(dy.transpose(0, 1).contiguous().cuda())
+    torch.cuda.synchronize()
+    assert (y.detach().transpose(0, 1).double().cpu() - ref_out).abs().max().item() < FWD_ATOL
+    for b in range(B):
+        assert torch.all(y[lens[b]:, b] == 0)
+
+    def close(name, got, want):
+        scale = max(want.abs().max().item(), 1e-3)
+        e = (got.double().cpu() - want).abs().max().item()
+        assert e < GRAD_RTOL * scale + 1e-6, f"{name}: err {e} scale {scale}"
+
+    close("dx", x_tm.grad.transpose(0, 1), ref_dx)
+    for name, p in ref.named_parameters():
+        close(name, getattr(hip, name).grad, p.grad)

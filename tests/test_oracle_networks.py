@@ -12,6 +12,10 @@ CONFIGS = {
                 dict(embedding_size=72, pad_token_id=0, hidden_size=128, output_size=128, num_layers=1, dropout=0.0), 72),
     "g2_stack": (dict(input_size=12, hidden_size=16, output_size=8, num_layers=2, dropout=0.0, bidirectional=True),
                  dict(embedding_size=10, pad_token_id=0, hidden_size=16, output_size=8, num_layers=2, dropout=0.0), 10),
+    "g3_gru": (dict(input_size=12, hidden_size=16, output_size=8, num_layers=2, rnn_type="gru", dropout=0.0, bidirectional=True),
+               dict(embedding_size=10, pad_token_id=0, hidden_size=16, output_size=8, num_layers=2, rnn_type="lstm", dropout=0.0), 10),
+    "g3_rnn": (dict(input_size=12, hidden_size=16, output_size=8, num_layers=2, rnn_type="rnn", dropout=0.0, bidirectional=True),
+               dict(embedding_size=10, pad_token_id=0, hidden_size=16, output_size=8, num_layers=1, rnn_type="gru", dropout=0.0), 10),
     "g2_uni": (dict(input_size=12, hidden_size=16, output_size=8, num_layers=2, dropout=0.0, bidirectional=False),
                dict(embedding_size=10, pad_token_id=0, hidden_size=16, output_size=8, num_layers=1, dropout=0.0), 10),
 }
