@@ -137,6 +137,8 @@ typedef struct rnnt_lstm_desc {
 } rnnt_lstm_desc;
 
 size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D);
+/* largest B one call accepts for (H, D, cell); 0 = shape unsupported.  Bigger batches: split along B (rows are independent). */
+int32_t rnnt_hip_lstm_max_batch(int32_t H, int32_t D, int32_t cell);
 int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream);
 
 typedef struct rnnt_lstm_bwd_desc {

@@ -1241,6 +1241,20 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
 
 using namespace rnnt;
 
+extern "C" int32_t rnnt_hip_lstm_max_batch(int32_t H, int32_t D, int32_t cell) {
+  // largest per-call batch the persistent kernels take for this shape (callers split bigger batches along B:
+  // sequences are independent, weight gradients add)
+  int cus = device_cus();
+  if (cus <= 0) cus = 256;
+  int best = 0;
+  for (int B = 64; B >= 1; --B) {
+    Plan2 p2;
+    Plan p1;
+    if (make_plan2(B, H, D, cus, &p2) || (cell == RNNT_CELL_LSTM && make_plan(B, H, D, cus, &p1))) { best = B; break; }
+  }
+  return best;
+}
+
 extern "C" size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D) {
   Plan pl;
   int cus = device_cus();

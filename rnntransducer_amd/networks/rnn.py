@@ -10,6 +10,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from ..ops import LstmStackFn
 
 
@@ -53,8 +54,20 @@ class HipLSTM(nn.Module):
         p = self.dropout if (self.training and self.num_layers > 1) else 0.0
         self._step += 1
         seed = (torch.initial_seed() * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFFFFFF
-        return LstmStackFn.apply(x_tm, lens, self.hidden_size, self.num_layers, self.bidirectional, p, seed, self.CELL,
-                                 *self.flat_weights())
+        B = x_tm.shape[1]
+        cap = _lib.lib().rnnt_hip_lstm_max_batch(self.hidden_size, 2 if self.bidirectional else 1, self.CELL)
+        if cap <= 0:
+            raise _lib.RnntHipError(f"hidden_size={self.hidden_size} does not fit the persistent recurrence kernels")
+        if B <= cap:
+            return LstmStackFn.apply(x_tm, lens, self.hidden_size, self.num_layers, self.bidirectional, p, seed, self.CELL,
+                                     *self.flat_weights())
+        # batch rows are independent: run slices of the batch back to back (autograd sums the weight gradients)
+        outs = []
+        for b0 in range(0, B, cap):
+            outs.append(LstmStackFn.apply(x_tm[:, b0:b0 + cap].contiguous(), lens[b0:b0 + cap].contiguous(), self.hidden_size,
+                                          self.num_layers, self.bidirectional, p, seed + 104729 * (b0 + 1), self.CELL,
+                                          *self.flat_weights()))
+        return torch.cat(outs, dim=1)
 
 
 class HipGRU(HipLSTM):

@@ -190,8 +190,6 @@ class LstmStackFn(torch.autograd.Function):
         T, B, I0 = x.shape
         D = 2 if bidirectional else 1
         H = hidden
-        if B > 64:
-            raise RnntHipError("per-GPU batch > 64 is not supported by the persistent LSTM kernel in this version")
         dev = x.device
         ws = lstm_workspace(T, B, max(I0, D * H), H, D, dev)
         saved = []

@@ -84,7 +84,7 @@ def test_lstm_dropout_mask_is_consistent_between_fwd_and_bwd():
     w = hip.flat_weights()
 
     def run(xx):
-        return LstmStackFn.apply(xx, lens, 16, 2, True, 0.5, 1234, *w)
+        return LstmStackFn.apply(xx, lens, 16, 2, True, 0.5, 1234, 0, *w)
 
     xr = x.clone().requires_grad_(True)
     proj = torch.randn(6, 3, 32, device="cuda")
@@ -194,3 +194,27 @@ def test_gru_and_elman_cells_fwd_bwd(cell, B, T, I, H, L, bi):
     close("dx", x_tm.grad.transpose(0, 1), ref_dx)
     for name, p in ref.named_parameters():
         close(name, getattr(hip, name).grad, p.grad)
+
+
+def test_batches_beyond_one_launch_are_split_along_b():
+    """B=70 LSTM (one launch takes <= 64 rows) and a 1024-wide GRU with B=20 (grouped form takes <= 16 rows at that width):
+    the module runs batch slices back to back; results equal the oracle."""
+    from rnntransducer_amd.networks.rnn import HipGRU, HipLSTM
+    for cls, ref_cls, (B, T, I, H) in ((HipLSTM, nn.LSTM, (70, 5, 8, 16)), (HipGRU, nn.GRU, (20, 6, 8, 1024))):
+        torch.manual_seed(B)
+        ref = ref_cls(I, H, 1, batch_first=True, bidirectional=True).double()
+        hip = cls(I, H, 1, bidirectional=True)
+        hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+        hip = hip.cuda()
+        g = torch.Generator().manual_seed(2)
+        lens = [T] + torch.randint(1, T + 1, (B - 1,), generator=g).tolist()
+        x = torch.randn(B, T, I, generator=g)
+        dy = torch.randn(B, T, 2 * H, generator=g)
+        ref_out, ref_dx = _oracle(x, lens, ref, dy)
+        x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
+        y = hip(x_tm, torch.tensor(lens, dtype=torch.int32, device="cuda"))
+        y.backward(dy.transpose(0, 1).contiguous().cuda())
+        assert (y.detach().transpose(0, 1).double().cpu() - ref_out).abs().max().item() < FWD_ATOL
+        for name, p in ref.named_parameters():
+            scale = max(p.grad.abs().max().item(), 1e-3)
+            assert (getattr(hip, name).grad.double().cpu() - p.grad).abs().max().item() < GRAD_RTOL * scale + 1e-6, name
