@@ -37,6 +37,8 @@ CONFIGS = {
     "c2": (32, 1000, 40, 72, (512, 4), (512, 1), 512),
     "c3": (8, 2000, 120, 72, (512, 4), (512, 1), 512),
     "c5": (16, 1500, 80, 2048, (640, 6), (640, 1), 640),
+    # the reference's SHIPPED config/config.json (8x1024 bi-GRU encoder, 2x1024 LSTM prediction net, O=512), B=16
+    "shipped": (16, 1000, 40, 72, (1024, 8, "gru"), (1024, 2, "lstm"), 512),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
@@ -46,9 +48,11 @@ def build_model(cfg, dropout, total_steps):
     from argparse import Namespace
 
     from rnntransducer_amd import RNNTransducer
-    B, T, U, V, (He, Le), (Hp, Lp), O = cfg
-    tn = dict(input_size=80, hidden_size=He, output_size=O, num_layers=Le, rnn_type="lstm", dropout=dropout, bidirectional=True)
-    pn = dict(embedding_size=V, hidden_size=Hp, output_size=O, num_layers=Lp, rnn_type="lstm", dropout=dropout)
+    B, T, U, V, enc, pred, O = cfg
+    He, Le, Te = (tuple(enc) + ("lstm",))[:3]
+    Hp, Lp, Tp = (tuple(pred) + ("lstm",))[:3]
+    tn = dict(input_size=80, hidden_size=He, output_size=O, num_layers=Le, rnn_type=Te, dropout=dropout, bidirectional=True)
+    pn = dict(embedding_size=V, hidden_size=Hp, output_size=O, num_layers=Lp, rnn_type=Tp, dropout=dropout)
     args = Namespace(learning_rate=1e-3, weight_decay=1e-4, warmup_ratio=0.2, final_div_factor=1e4, total_steps=total_steps,
                      move_metrics_to_cpu=False)
     torch.manual_seed(0)  # same initial weights on every rank (DDP broadcasts rank 0's; same seed is equivalent)
@@ -180,8 +184,8 @@ def main():
         "metric": "utterances/sec", "value": round(world * B * a.steps / dt, 3), "unit": "utt/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{list(CONFIGS).index(a.config)}] {a.config}: full train step, B={B}/GPU T={T} "
-                               f"(10 ms frames x 80 mel) U={U} V={V}, enc {cfg[4][1]}x{cfg[4][0]} bi-LSTM, pred {cfg[5][1]}x{cfg[5][0]} LSTM, "
+        "config": {"workload": f"{'BASELINE configs[%d]' % (list(CONFIGS).index(a.config) + (1 if a.config == 'c5' else 0)) if a.config != 'shipped' else 'reference config.json'} {a.config}: full train step, B={B}/GPU T={T} "
+                               f"(10 ms frames x 80 mel) U={U} V={V}, enc {cfg[4][1]}x{cfg[4][0]} bi-{tn['rnn_type'].upper()}, pred {cfg[5][1]}x{cfg[5][0]} {pn['rnn_type'].upper()}, "
                                f"O={cfg[6]}, dropout {a.dropout}, {'ragged' if a.ragged else 'fixed'} lengths",
                    "global_batch": world * B, "parallelism": f"dp{world}", "grad_allreduce_bytes": flat.bytes()},
         "last_loss": round(last_loss, 4), "roofline": roof, "kernels": kernels,
