@@ -157,6 +157,15 @@ def main():
         if cnt[i]:
             kernels[name] = {"launches": int(cnt[i]), "ms_total": round(ms[i], 3), "avg_us": round(1e3 * ms[i] / cnt[i], 2),
                              "work_per_launch": work[i] / cnt[i]}
+    for name, kd_ in kernels.items():  # every kernel kind against its own roofline (GEMM: fp32 MFMA; the rest: HBM)
+        sec = kd_["ms_total"] / kd_["launches"] / 1e3
+        if name == "gemm_f32_kernel":
+            kd_["tflops"] = round(kd_["work_per_launch"] / sec / 1e12, 2)
+            kd_["frac_of_mfma_peak"] = round(kd_["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        else:
+            kd_["gbs"] = round(kd_["work_per_launch"] / sec / 1e9, 1)
+            kd_["frac_of_hbm_peak"] = round(kd_["gbs"] / PEAK_HBM_GBS, 5)
+        kd_["ms_per_step"] = round(kd_["ms_total"] / a.steps, 3)
     dom = max((k for k in kernels if k != "misc"), key=lambda k: kernels[k]["ms_total"])
     kd = kernels[dom]
     per_launch_s = kd["ms_total"] / kd["launches"] / 1e3
