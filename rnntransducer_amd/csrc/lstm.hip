@@ -62,6 +62,7 @@ struct LstmK {
   float* aux;      // GRU backward: hidden-side gate gradients (T,B,D,4H) for dW_hh / db_hh
   unsigned* xcc;   // v2: [D*G][NC] XCC id + 1 of every member, published once at kernel start (zeroed per launch)
   int allow_local; // v2: permit the L2-local exchange when a group is verified to sit on one XCD
+  int hw_math;     // v2: v_exp_f32 / v_rcp_f32 cell math (RNNT_LSTM_HW_MATH=1) instead of ocml expf + IEEE division
 };
 
 #define DBG_STAMP(i) do { if (p.dbg && tid == 0) { const unsigned long long now_ = clock64(); dsum[i] += now_ - dlast; dlast = now_; } } while (0)
@@ -79,6 +80,8 @@ __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned l
   h ^= h >> 16;
   return h;
 }
+__device__ __forceinline__ float sig_sel(float x, int hw) { return hw ? sigmoid_hw(x) : sigmoidf_(x); }
+__device__ __forceinline__ float tanh_sel(float x, int hw) { return hw ? tanh_hw(x) : tanh_e(x); }
 // value of lane (l + n) within the same 16-lane row (n = 4, 8, 12): one DPP move, no LDS round trip
 template <int CTRL>
 __device__ __forceinline__ float row_shl(float x) {
@@ -666,20 +669,20 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
       if (active) {
         if constexpr (CELL == 0) {
           const f32x4 g4 = xp + rec;
-          const float ig = sigmoid_hw(g4[0]), fg = sigmoid_hw(g4[1]), gg = tanh_hw(g4[2]), og = sigmoid_hw(g4[3]);
+          const float ig = sig_sel(g4[0], p.hw_math), fg = sig_sel(g4[1], p.hw_math), gg = tanh_sel(g4[2], p.hw_math), og = sig_sel(g4[3], p.hw_math);
           c_state = fg * c_state + ig * gg;
-          hval = og * tanh_hw(c_state);
+          hval = og * tanh_sel(c_state, p.hw_math);
           gact = (f32x4){ig, fg, gg, og};
         } else if constexpr (CELL == 1) {
-          const float rg = sigmoid_hw(xp[0] + rec[0]), zg = sigmoid_hw(xp[1] + rec[1]);
+          const float rg = sig_sel(xp[0] + rec[0], p.hw_math), zg = sig_sel(xp[1] + rec[1], p.hw_math);
           const float hn = rec[2] + bhn;
-          const float ng = tanh_hw(xp[2] + rg * hn);
+          const float ng = tanh_sel(xp[2] + rg * hn, p.hw_math);
           hval = (1.f - zg) * ng + zg * c_state;
           c_state = hval;
           gact = (f32x4){rg, zg, ng, hn};
         } else {
           const float pre = xp[0] + rec[0];
-          hval = (p.cell == RNNT_CELL_RNN_RELU) ? fmaxf(pre, 0.f) : tanh_hw(pre);
+          hval = (p.cell == RNNT_CELL_RNN_RELU) ? fmaxf(pre, 0.f) : tanh_sel(pre, p.hw_math);
           c_state = hval;
           gact = (f32x4){hval, 0.f, 0.f, 0.f};
         }
@@ -837,7 +840,7 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
       if (active) {
         if constexpr (CELL == 0) {
           const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
-          const float tc = tanh_hw(c_t);
+          const float tc = tanh_sel(c_t, p.hw_math);
           const float dc = dh * og * (1.f - tc * tc) + dc_carry;
           dg4[0] = dc * gg * ig * (1.f - ig);
           dg4[1] = dc * c_p * fg * (1.f - fg);
@@ -1234,6 +1237,7 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->dbg = getenv("RNNT_LSTM_DBG") ? w.dbg : nullptr;
   k->xcc = w.flags + 16 + w.nflags;
   k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
+  k->hw_math = getenv("RNNT_LSTM_HW_MATH") ? 1 : 0;
 }
 
 }  // namespace
