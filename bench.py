@@ -109,7 +109,14 @@ def main():
     B, T, U, V = cfg[:4]
     model, tn, pn = build_model(cfg, a.dropout, max(100, a.warmup + a.steps + 1))
     model = model.to(dev).train()
-    batch = synthetic_batch(B, T, U, V, ragged=a.ragged, seed=1234 + rank, device=dev)
+    t_lengths = None
+    if a.ragged:
+        # ONE global batch of world*B ragged utterances, sorted by length (descending) and dealt
+        # indices[rank::world] (the behaviour of the reference's datasampler.py:74-99), so every rank sees a similar T profile
+        from rnntransducer_amd.data import global_ragged_lengths, length_grouped_indices
+        glob = global_ragged_lengths(world * B, T)
+        t_lengths = [glob[i] for i in length_grouped_indices(glob, rank, world)]
+    batch = synthetic_batch(B, T, U, V, ragged=a.ragged, seed=1234 + rank, device=dev, t_lengths=t_lengths)
     conf = model.configure_optimizers()
     opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
     flat = FlatGradAllReduce(model.parameters())

@@ -7,12 +7,16 @@ import torch
 
 
 def synthetic_batch(B: int, T: int, U: int, V: int, n_mels: int = 80, ragged: bool = False, seed: int = 1234,
-                    blank: int = 0, device="cpu"):
+                    blank: int = 0, device="cpu", t_lengths=None):
     """(input_audios f32 (B,T,n_mels), audio_lengths list, tensor_audio_lengths i32 (B,), input_texts i64 (B,U+1),
     text_lengths list, targets i32 (B,U), target_lengths i32 (B,)) — frames beyond T_b are 0.0, labels in 1..V-1."""
     g = torch.Generator().manual_seed(seed)
     audios = torch.randn(B, T, n_mels, generator=g)
-    if ragged:
+    if t_lengths is not None:  # lengths decided by the caller (e.g. a rank's share of a length-sorted global batch)
+        t_list = [int(t) for t in t_lengths]
+        assert len(t_list) == B and max(t_list) <= T and min(t_list) >= 1
+        u_list = [max(1, min(U, round(U * t / T))) for t in t_list]
+    elif ragged:
         t_list = torch.randint(max(1, T // 2), T + 1, (B,), generator=g).tolist()
         t_list[0] = T
         u_list = [max(1, round(U * t / T)) for t in t_list]
@@ -26,6 +30,14 @@ def synthetic_batch(B: int, T: int, U: int, V: int, n_mels: int = 80, ragged: bo
     texts = torch.cat([torch.full((B, 1), blank, dtype=torch.int64), targets.to(torch.int64)], dim=1)
     return (audios.to(device), t_list, torch.tensor(t_list, dtype=torch.int32, device=device), texts.to(device),
             [u + 1 for u in u_list], targets.to(device), torch.tensor(u_list, dtype=torch.int32, device=device))
+
+
+def global_ragged_lengths(n: int, T: int, seed: int = 1234) -> List[int]:
+    """Frame counts of a global batch of n KsponSpeech-shaped utterances: U{T/2..T}, at least one at T."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(max(1, T // 2), T + 1, (n,), generator=g).tolist()
+    t[0] = T
+    return t
 
 
 def length_grouped_indices(lengths: Sequence[int], rank: int, world: int) -> List[int]:

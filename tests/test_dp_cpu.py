@@ -76,3 +76,19 @@ def test_synthetic_batch_follows_dataloader_contract():
         assert torch.all(targets[b, :int(u_len[b])] > 0) and torch.all(targets[b, int(u_len[b]):] == 0)
         assert torch.equal(texts[b, 1:], targets[b].long())
     assert max(a_list) == 50 and int(u_len.max()) == 10
+
+
+def test_c4_global_batch_is_dealt_so_ranks_get_matching_length_profiles():
+    from rnntransducer_amd.data import global_ragged_lengths
+    world, B, T = 4, 8, 1000
+    glob = global_ragged_lengths(world * B, T)
+    shares = [[glob[i] for i in length_grouped_indices(glob, r, world)] for r in range(world)]
+    assert sorted(sum(shares, []), reverse=True) == sorted(glob, reverse=True)      # a partition of the global batch
+    for s in shares:
+        assert s == sorted(s, reverse=True) and len(s) == B
+    # rank-strided deal of a sorted list: every rank's k-th longest is within one sort position of the others'
+    for k in range(B):
+        col = [s[k] for s in shares]
+        assert max(col) - min(col) <= max(glob[i] - glob[j] for i in range(1) for j in range(1)) + (sorted(glob, reverse=True)[k * world] - sorted(glob, reverse=True)[k * world + world - 1])
+    batch = synthetic_batch(B, T, 40, 72, t_lengths=shares[1], seed=5)
+    assert batch[1] == shares[1] and all(1 <= u <= 40 for u in batch[6].tolist())
