@@ -204,6 +204,12 @@ int rnnt_hip_loss_from_logits_fwd_bwd_ex(const void* logits, int32_t dtype, cons
                                          float gscale, float* nll, void* grad, void* workspace, size_t workspace_bytes,
                                          void* stream);
 
+/* One fused AdamW step over FLAT fp32 buffers (all parameters / gradients / moments of the module laid out back to back):
+ * replaces torch.optim.AdamW's multi-tensor kernels at model.py:111-115.  Same update as torch (decoupled weight decay,
+ * bias corrections from `step` >= 1). */
+int rnnt_hip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int64_t step, void* stream);
+
 /* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients: fc.bias, out_proj.bias, LSTM biases).
  * Two-stage fixed-order reduction; workspace = rnnt_hip_colsum_workspace_bytes(M, N) bytes. */
 size_t rnnt_hip_colsum_workspace_bytes(int64_t M, int64_t N);

@@ -68,6 +68,8 @@ SYMBOLS = {
     "rnnt_hip_loss_from_logits_fwd_bwd_ex": (C.c_int, [C.c_void_p, c_i32, C.c_void_p, C.c_void_p, C.c_void_p, c_i32, c_i32,
                                                         c_i32, c_i32, c_i32, C.c_float, C.c_void_p, C.c_void_p,
                                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnnt_hip_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, c_i64, C.c_void_p]),
     "rnnt_hip_embedding_fwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p]),
     "rnnt_hip_colsum_workspace_bytes": (C.c_size_t, [c_i64, c_i64]),
     "rnnt_hip_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

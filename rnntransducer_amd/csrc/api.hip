@@ -1,6 +1,8 @@
 // Error plumbing + version of librnnt_hip (C ABI in include/rnnt_hip.h).
 #include "common.hpp"
 
+#include <math.h>
+
 #include <mutex>
 #include <vector>
 
@@ -66,6 +68,56 @@ extern "C" int rnnt_hip_prof_collect(double* ms, double* work, int64_t* count, i
     if (r.b) g_pool.push_back(r.b);
   }
   g_prof.clear();
+  return RNNT_OK;
+}
+
+namespace rnnt {
+namespace {
+// torch.optim.AdamW step (decoupled weight decay) over flat fp32 buffers, same operation order as torch's single-tensor
+// path: p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void __launch_bounds__(256) adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                          float wd, float step_size, float bc2_sqrt) {
+  const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    f32x4 pp = *reinterpret_cast<f32x4*>(p + i4), gg = *reinterpret_cast<const f32x4*>(g + i4);
+    f32x4 mm = *reinterpret_cast<f32x4*>(m + i4), vv = *reinterpret_cast<f32x4*>(v + i4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pp[e] *= 1.0f - lr * wd;
+      mm[e] += (gg[e] - mm[e]) * (1.0f - b1);
+      vv[e] = vv[e] * b2 + (1.0f - b2) * gg[e] * gg[e];
+      pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) / bc2_sqrt + eps));
+    }
+    *reinterpret_cast<f32x4*>(p + i4) = pp;
+    *reinterpret_cast<f32x4*>(m + i4) = mm;
+    *reinterpret_cast<f32x4*>(v + i4) = vv;
+  } else {
+    for (long i = i4; i < n; ++i) {
+      float pp = p[i] * (1.0f - lr * wd);
+      const float gg = g[i];
+      const float mm = m[i] + (gg - m[i]) * (1.0f - b1);
+      const float vv = v[i] * b2 + (1.0f - b2) * gg * gg;
+      pp -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+      p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+  }
+}
+}  // namespace
+}  // namespace rnnt
+
+extern "C" int rnnt_hip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                   float eps, float weight_decay, int64_t step, void* stream) {
+  using namespace rnnt;
+  RNNT_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "adamw: bad arguments");
+  RNNT_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                   reinterpret_cast<uintptr_t>(v)) & 15) == 0, "adamw: buffers must be 16-byte aligned");
+  if (n == 0) return RNNT_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  ProfScope prof(RNNT_K_MISC, 28.0 * (double)n, (hipStream_t)stream);
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)ceil_div(ceil_div(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (long)n, lr, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)sqrt(bc2));
+  RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }
 

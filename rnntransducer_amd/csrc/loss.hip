@@ -134,14 +134,22 @@ __device__ __forceinline__ double logaddexp_d(double a, double b) {
   const double m = fmax(a, b);
   if (m == NEG_INF) return NEG_INF;
   const float d = (float)(fmin(a, b) - m);  // <= 0, -inf allowed
-  return m + (double)log1pf(expf(d));
+  // fp32 correction term in [0, ln 2]: hardware exp/log (abs err ~1e-7) -- the fp64 running sums keep the lattice exact
+  return m + (double)__logf(1.0f + __expf(d));
 }
+// neighbour hand-off across the whole wavefront by DPP (wave_shr:1 / wave_shl:1): two moves per fp64, no LDS permute
 __device__ __forceinline__ double shfl_up1(double x, int lane) {
-  double y = __shfl_up(x, 1);
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, false);
+  const double y = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
   return lane == 0 ? NEG_INF : y;
 }
 __device__ __forceinline__ double shfl_down1(double x, int lane) {
-  double y = __shfl_down(x, 1);
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, false);
+  const double y = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
   return lane == 63 ? NEG_INF : y;
 }
 

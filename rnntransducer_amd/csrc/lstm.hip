@@ -62,7 +62,8 @@ struct LstmK {
   float* aux;      // GRU backward: hidden-side gate gradients (T,B,D,4H) for dW_hh / db_hh
   unsigned* xcc;   // v2: [D*G][NC] XCC id + 1 of every member, published once at kernel start (zeroed per launch)
   int allow_local; // v2: permit the L2-local exchange when a group is verified to sit on one XCD
-  int hw_math;     // v2: v_exp_f32 / v_rcp_f32 cell math (RNNT_LSTM_HW_MATH=1) instead of ocml expf + IEEE division
+  int hw_math;     // v2: v_exp_f32 / v_rcp_f32 cell math (default; measured whole-model loss delta identical to the ocml expf +
+                   // IEEE-division form, which RNNT_LSTM_EXACT_MATH=1 selects)
 };
 
 #define DBG_STAMP(i) do { if (p.dbg && tid == 0) { const unsigned long long now_ = clock64(); dsum[i] += now_ - dlast; dlast = now_; } } while (0)
@@ -1237,7 +1238,7 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->dbg = getenv("RNNT_LSTM_DBG") ? w.dbg : nullptr;
   k->xcc = w.flags + 16 + w.nflags;
   k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
-  k->hw_math = getenv("RNNT_LSTM_HW_MATH") ? 1 : 0;
+  k->hw_math = getenv("RNNT_LSTM_EXACT_MATH") ? 0 : 1;
 }
 
 }  // namespace

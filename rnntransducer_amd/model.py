@@ -69,8 +69,13 @@ class RNNTransducer(_Base):
         return {"loss": loss}
 
     def configure_optimizers(self):
-        optimizer = torch.optim.AdamW([{"params": [p for p in self.parameters()], "name": "OneCycleLR"}],
-                                      lr=self.args.learning_rate, weight_decay=self.args.weight_decay)
+        group = [{"params": [p for p in self.parameters()], "name": "OneCycleLR"}]
+        if next(self.parameters()).is_cuda:
+            # same optimiser, same hyper-parameters: parameters/gradients/moments flattened, one fused HIP step
+            from .optim import FlatAdamW
+            optimizer = FlatAdamW(group, lr=self.args.learning_rate, weight_decay=self.args.weight_decay)
+        else:
+            optimizer = torch.optim.AdamW(group, lr=self.args.learning_rate, weight_decay=self.args.weight_decay)
         trainer = getattr(self, "_trainer", None)
         total = trainer.estimated_stepping_batches if trainer is not None else int(getattr(self.args, "total_steps"))
         scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=self.args.learning_rate, total_steps=total,

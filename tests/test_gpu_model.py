@@ -117,3 +117,29 @@ def test_optimizer_contract_and_one_adamw_step_changes_loss():
         conf["lr_scheduler"]["scheduler"].step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+def test_flat_adamw_matches_torch_adamw_step_for_step():
+    """FlatAdamW (one fused HIP kernel over flat buffers) vs torch.optim.AdamW on identical parameters/gradients,
+    driven by the same OneCycleLR schedule, 5 steps."""
+    from rnntransducer_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    shapes = [(7, 5), (13,), (4, 3, 2), (1,), (130, 70)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    hip_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, lr=1e-2, weight_decay=1e-2)
+    hip = FlatAdamW(hip_p, lr=1e-2, weight_decay=1e-2)
+    assert isinstance(hip, torch.optim.AdamW)
+    s_ref = torch.optim.lr_scheduler.OneCycleLR(ref, max_lr=1e-2, total_steps=20, pct_start=0.2)
+    s_hip = torch.optim.lr_scheduler.OneCycleLR(hip, max_lr=1e-2, total_steps=20, pct_start=0.2)
+    for it in range(5):
+        hip.zero_grad()
+        for a, b in zip(ref_p, hip_p):
+            gr = torch.randn_like(a) * (it + 1)
+            a.grad = gr.clone()
+            b.grad += gr.cuda()          # accumulates into the flat view, like autograd does
+        ref.step(); hip.step(); s_ref.step(); s_hip.step()
+    for a, b in zip(ref_p, hip_p):
+        assert (a.detach() - b.detach().cpu()).abs().max().item() < 2e-6
+    sd = hip.state_dict()
+    assert len(sd["state"]) == len(shapes) and "exp_avg" in sd["state"][0]
