@@ -40,6 +40,7 @@ CONFIGS = {
     # the reference's SHIPPED config/config.json (8x1024 bi-GRU encoder, 2x1024 LSTM prediction net, O=512), B=16
     "shipped": (16, 1000, 40, 72, (1024, 8, "gru"), (1024, 2, "lstm"), 512),
 }
+GRAD_PROBES = ("fc.weight", "encoder.rnn.weight_hh_l0", "decoder.embedding.weight")  # SURVEY §8(d) "Loss delta" row
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
 
@@ -71,9 +72,10 @@ def cpu_baseline(model, tn, pn, V, batch, sample_b, threads):
     t0 = time.perf_counter()
     loss = training_loss(oracle, sub)
     loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in oracle.named_parameters() if k in GRAD_PROBES}
     opt.step()
     dt = time.perf_counter() - t0
-    return sample_b / dt, float(loss), dt
+    return sample_b / dt, float(loss.detach()), dt, grads
 
 
 def main():
@@ -138,6 +140,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     L = _lib.lib()
     L.rnnt_hip_prof_enable(1)
     fence()
@@ -206,17 +210,28 @@ def main():
                    "global_batch": world * B, "parallelism": f"dp{world}", "grad_allreduce_bytes": opt.grad_bytes()},
         "last_loss": round(last_loss, 4), "roofline": roof, "kernels": kernels,
     }
+    # the step must run without any (B,T,U+1,V) or (B,T,U+1,2*O) tensor; peak allocator bytes over the
+    # timed region vs what the reference's joint materialises (networks/transducer.py:61-69)
+    O = cfg[6]
+    out["memory"] = {"peak_allocated_bytes": int(torch.cuda.max_memory_allocated()),
+                     "reference_concat_bytes_per_copy": int(B) * T * (U + 1) * 2 * O * 4,
+                     "reference_logits_bytes": int(B) * T * (U + 1) * V * 4,
+                     "stash_note": "peak is dominated by the LSTM stash (activated gates, 16*H bytes per frame per direction per layer)"}
 
     if world == 1 and not a.no_cpu_baseline:
         # loss parity on the sample: HIP with dropout off vs the oracle (same weights, same utterances)
         nb = min(a.cpu_sample, B)
-        model.eval()
-        with torch.no_grad():
-            sub = tuple((x[:nb] if isinstance(x, torch.Tensor) else x[:nb]) for x in batch)
-            # weights moved during the timed steps: compare on the CURRENT weights
-            hip_loss = float(model.jointnet.loss(sub[0], sub[2], sub[3], sub[5], sub[6], model.blank_token_id).mean())
+        model.eval()  # dropout off; weights moved during the timed steps: compare on the CURRENT weights
+        sub = tuple((x[:nb] if isinstance(x, torch.Tensor) else x[:nb]) for x in batch)
+        opt.zero_grad()
+        hip_l = model.jointnet.loss(sub[0], sub[2], sub[3], sub[5], sub[6], model.blank_token_id).mean()
+        hip_l.backward()
+        hip_loss = float(hip_l.detach())
+        hip_grads = {k: p.grad.detach().cpu().clone() for k, p in model.jointnet.named_parameters() if k in GRAD_PROBES}
         model.train()
-        v, oracle_loss, secs = cpu_baseline(model, tn, pn, V, batch, nb, a.cpu_threads)
+        v, oracle_loss, secs, ref_grads = cpu_baseline(model, tn, pn, V, batch, nb, a.cpu_threads)
+        out["grad_max_abs_dev"] = {k: {"max_abs_dev": float((hip_grads[k] - ref_grads[k]).abs().max()),
+                                       "ref_max_abs": float(ref_grads[k].abs().max())} for k in GRAD_PROBES}
         out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": a.cpu_threads, "kind": "port",
                                "sample": f"1 full train step (fwd+RNN-T loss+bwd+AdamW) of the oracle on {nb} utterances of the same "
                                          f"workload, {secs:.1f} s, torch.set_num_threads({a.cpu_threads})"}

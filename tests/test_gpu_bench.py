@@ -27,6 +27,10 @@ def test_bench_emits_one_contract_line_with_roofline_and_cpu_baseline():
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 4 and j["cpu_baseline"]["value"] > 0
     assert j["loss_rel_delta"] < 1e-4          # north_star tolerance on the whole path (mel, label) -> loss
     assert "workload" in j["config"] and "model" not in j["config"]
+    assert set(j["grad_max_abs_dev"]) == {"fc.weight", "encoder.rnn.weight_hh_l0", "decoder.embedding.weight"}
+    for v in j["grad_max_abs_dev"].values():
+        assert v["max_abs_dev"] <= 1e-3 * max(v["ref_max_abs"], 1e-3)
+    assert j["memory"]["peak_allocated_bytes"] > 0
 
 
 def test_smoke_entry_point():
