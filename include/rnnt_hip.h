@@ -221,6 +221,37 @@ int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float*
 int rnnt_hip_embedding_bwd(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V, int64_t padding_idx,
                            float* dW, void* stream);
 
+/* Greedy decoding on device (replaces JointNet.recognize_greedy, networks/transducer.py:95-145, including its
+ * single-step prediction-net call networks/decoder.py:121-123 and the 1-D joint networks/transducer.py:64-69).
+ * One workgroup per utterance.  A = gelu(encoder_outputs) . fc.weight[:, :O_enc]^T + fc.bias for every frame
+ * (time-major (T,B,V); computed by the caller with rnnt_hip_gemm_f32(RNNT_GEMM_GELU_A)).  Utterance b visits frames
+ * t in [0, t_lens[b]) — the reference decodes one utterance per call, so its loop bound encoder_outputs.size(1) is that
+ * utterance's own length; t_lens == NULL visits all T padded frames (what a batched reference call does).  Per frame: up to max_iters symbols; a symbol equal to the
+ * last appended one still advances the prediction net but is not appended (transducer.py:132-137).
+ * tokens (B,max_out) int64 (entries past ntok[b] are left untouched), ntok (B) int32; max_out >= T*max_iters never
+ * truncates. */
+#define RNNT_DECODE_MAX_LAYERS 8
+typedef struct rnnt_decode_desc {
+  int32_t T, B, V;       /* frames, utterances, vocabulary */
+  int32_t Hp, O, L;      /* prediction-net hidden size (= embedding width), joint input width per side, layers */
+  int32_t cell;          /* RNNT_CELL_* */
+  int32_t blank, max_iters, max_out;
+  const float* A;        /* (T,B,V) */
+  const int32_t* t_lens; /* (B) device, or NULL */
+  const float* emb;      /* (V,Hp)  decoder.embedding.weight */
+  const float* w_ih[RNNT_DECODE_MAX_LAYERS]; /* (G*Hp,Hp) decoder.rnn.weight_ih_l{k} */
+  const float* w_hh[RNNT_DECODE_MAX_LAYERS];
+  const float* b_ih[RNNT_DECODE_MAX_LAYERS];
+  const float* b_hh[RNNT_DECODE_MAX_LAYERS];
+  const float* w_o;      /* (O,Hp)  decoder.out_proj.weight */
+  const float* b_o;      /* (O) */
+  const float* w_d;      /* fc.weight[:, O_enc:]  (V,O), row stride ld_d floats */
+  int64_t ld_d;
+  int64_t* tokens;
+  int32_t* ntok;
+} rnnt_decode_desc;
+int rnnt_hip_greedy_decode(const rnnt_decode_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

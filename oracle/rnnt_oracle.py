@@ -213,6 +213,42 @@ class OracleJointNet(nn.Module):
     def forward(self, audios, audio_lens, texts, text_lens):
         return self.joint(self.encoder(audios, audio_lens), self.decoder(texts, text_lens))
 
+    @torch.no_grad()
+    def recognize_greedy(self, audios, audio_lens, blank: int, max_iters: int = 3, return_margin: bool = False,
+                         visit_padded_frames: bool = False):
+        """Greedy search restated from networks/transducer.py:95-145 (decoder single step: decoder.py:121-123; 1-D joint:
+        transducer.py:64-69).  Per utterance: prediction net primed with [[blank]] and zero state; for every frame of the
+        utterance (the reference decodes one utterance per call, so transducer.py:115's max_length is its own length;
+        visit_padded_frames=True walks the padded batch length instead, as a batched reference call would) up to
+        `max_iters` symbols: argmax of the joint (softmax dropped: monotone);
+        blank ends the frame; a non-blank symbol is appended unless it repeats the last appended one (:132-133), and
+        always advances the prediction net (:135-136).  Returns one python list per utterance (the reference stacks them,
+        which only works for B == 1) and optionally the smallest top-1/top-2 logit gap seen (how robust the argmax
+        decisions are to fp32 rounding)."""
+        enc = self.encoder(audios, audio_lens)  # (B,T,Oe)
+        dec_net = self.decoder
+        out, margin = [], float("inf")
+        for b in range(enc.size(0)):
+            toks, last = [], blank
+            emb = dec_net.embedding(torch.tensor([[blank]], dtype=torch.long))
+            y, state = dec_net.rnn(emb, None)
+            d = dec_net.out_proj(y).view(-1)
+            for t in range(enc.size(1) if visit_padded_frames else int(audio_lens[b])):
+                for _ in range(max_iters):
+                    z = self.fc(F.gelu(torch.cat((enc[b, t], d)), approximate="tanh"))
+                    top2 = torch.topk(z, 2).values
+                    margin = min(margin, float(top2[0] - top2[1]))
+                    k = int(z.argmax())
+                    if k == blank:
+                        break
+                    if k != last:
+                        toks.append(k)
+                        last = k
+                    y, state = dec_net.rnn(dec_net.embedding(torch.tensor([[k]], dtype=torch.long)), state)
+                    d = dec_net.out_proj(y).view(-1)
+            out.append(toks)
+        return (out, margin) if return_margin else out
+
 
 def training_loss(net: OracleJointNet, batch, blank: int = 0) -> torch.Tensor:
     """model.py:54-57 restated: unpack the 7-tuple, forward, mean RNN-T loss."""

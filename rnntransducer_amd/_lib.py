@@ -41,6 +41,18 @@ class LstmBwdDesc(C.Structure):
                 ("dw_hh", C.c_void_p * 2), ("db", C.c_void_p * 2), ("db_hh", C.c_void_p * 2)]
 
 
+DECODE_MAX_LAYERS = 8
+
+
+class DecodeDesc(C.Structure):
+    _fields_ = [("T", c_i32), ("B", c_i32), ("V", c_i32), ("Hp", c_i32), ("O", c_i32), ("L", c_i32), ("cell", c_i32),
+                ("blank", c_i32), ("max_iters", c_i32), ("max_out", c_i32), ("A", C.c_void_p), ("t_lens", C.c_void_p), ("emb", C.c_void_p),
+                ("w_ih", C.c_void_p * DECODE_MAX_LAYERS), ("w_hh", C.c_void_p * DECODE_MAX_LAYERS),
+                ("b_ih", C.c_void_p * DECODE_MAX_LAYERS), ("b_hh", C.c_void_p * DECODE_MAX_LAYERS),
+                ("w_o", C.c_void_p), ("b_o", C.c_void_p), ("w_d", C.c_void_p), ("ld_d", c_i64),
+                ("tokens", C.c_void_p), ("ntok", C.c_void_p)]
+
+
 # every symbol include/rnnt_hip.h declares: (name, restype, argtypes)
 SYMBOLS = {
     "rnnt_hip_version": (C.c_int, []),
@@ -74,6 +86,7 @@ SYMBOLS = {
     "rnnt_hip_colsum_workspace_bytes": (C.c_size_t, [c_i64, c_i64]),
     "rnnt_hip_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_embedding_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, c_i64, C.c_void_p, C.c_void_p]),
+    "rnnt_hip_greedy_decode": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
 }
 
 KERNEL_KINDS = ["gemm_f32_kernel", "lstm_fwd_kernel", "lstm_bwd_kernel", "lse_kernel", "alphabeta_kernel",

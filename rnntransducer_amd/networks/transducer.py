@@ -7,12 +7,13 @@ The reference's joint materialises (B,T,U+1,2*O) three times; here logits[b,t,u,
 with A = gelu(enc) W_e^T, C = gelu(dec) W_d^T (GELU is element-wise, fc is linear: SURVEY.md §0), so:
   * `loss(...)`  — fused joint + log-softmax + alpha/beta + gradient; (B,T,U+1,V) is never built;
   * `joint()/forward()` — still return the full logits tensor for callers that ask for it.
-Greedy/beam decoding (transducer.py:95-361) is out of scope.
+`recognize_greedy` (transducer.py:95-145) runs as ONE kernel launch (a workgroup per utterance, csrc/decode.hip) instead of
+a host loop with a device sync per symbol; beam search (transducer.py:147-361) stays out of scope.
 """
 import torch
 import torch.nn as nn
 
-from ..ops import JointLogitsFn, JointLossFn
+from ..ops import JointLogitsFn, JointLossFn, greedy_decode
 from .decoder import TextPredNet
 from .encoder import AudioTransNet, HipLinear, lengths_to_device
 
@@ -49,3 +50,25 @@ class JointNet(nn.Module):
         enc = self.encoder.forward_time_major(input_audios, t_lens)
         dec = self.decoder.forward_time_major(input_texts, u_lens + 1)  # text length = label length + 1 (dataloader.py:39-40)
         return JointLossFn.apply(enc, dec, self.fc.weight, self.fc.bias, targets, t_lens, u_lens, blank)
+
+    @torch.no_grad()
+    def recognize_greedy(self, inputs: torch.Tensor, inputs_lengths, blank_token_id: int, max_iters: int = 3,
+                         visit_padded_frames: bool = False):
+        """Greedy search, same result as transducer.py:95-145: per frame up to `max_iters` non-blank symbols, a symbol
+        equal to the previously appended one is dropped (but still advances the prediction net).  Returns a LongTensor
+        (1, n) for a single utterance, as the reference's `torch.stack` does.  For B > 1 (where the reference's stack
+        raises on ragged outputs) a list of B 1-D LongTensors, each equal to what the reference returns for that
+        utterance decoded alone; `visit_padded_frames=True` instead walks all max(lengths) frames for every utterance,
+        which is what the reference's loop bound (transducer.py:115,121) does inside a batched call."""
+        if self.training:
+            raise RuntimeError("recognize_greedy expects eval() mode (dropout inactive), like the reference's validation_step")
+        dev = inputs.device
+        t_lens = lengths_to_device(inputs_lengths, dev)
+        enc = self.encoder.forward_time_major(inputs, t_lens)
+        dec = self.decoder
+        tokens, ntok = greedy_decode(enc, self.fc.weight, self.fc.bias, dec.embedding.weight, dec.rnn.flat_weights(),
+                                     dec.rnn.CELL, dec.out_proj.weight, dec.out_proj.bias, blank_token_id, max_iters,
+                                     None if visit_padded_frames else t_lens)
+        n = ntok.tolist()  # the only host sync of the decode
+        outs = [tokens[b, :n[b]] for b in range(tokens.shape[0])]
+        return outs[0].unsqueeze(0) if len(outs) == 1 else outs

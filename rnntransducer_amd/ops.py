@@ -390,3 +390,42 @@ class RnntLossFromLogitsFn(torch.autograd.Function):
         grad = ctx.grad
         ctx.grad = None
         return (grad.float() * g.to(torch.float32).view(-1, 1, 1, 1)).to(grad.dtype), None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# greedy decoding (replaces the host loop of transducer.py:95-145)
+# --------------------------------------------------------------------------------------------------
+def greedy_decode(enc_tm: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor, emb_w: torch.Tensor, rnn_weights,
+                  cell: int, out_w: torch.Tensor, out_b: torch.Tensor, blank: int, max_iters: int,
+                  t_lens: Optional[torch.Tensor] = None):
+    """enc_tm (T,B,Oe) encoder outputs (time-major) -> (tokens (B, T*max_iters) int64, ntok (B,) int32), all on device.
+    rnn_weights: [w_ih, w_hh, b_ih, b_hh] per prediction-net layer; t_lens (B) int32 on device = frames visited per
+    utterance (None: all T)."""
+    _need_gpu(enc_tm, fc_w, emb_w)
+    enc_tm = _f32c(enc_tm, "encoder outputs")
+    T, B, Oe = enc_tm.shape
+    V, Ocat = fc_w.shape
+    Od = Ocat - Oe
+    Hp = emb_w.shape[1]
+    L = len(rnn_weights) // 4
+    if L > _lib.DECODE_MAX_LAYERS:
+        raise ValueError(f"greedy decode supports at most {_lib.DECODE_MAX_LAYERS} prediction-net layers")
+    A = torch.empty(T, B, V, device=enc_tm.device, dtype=torch.float32)
+    gemm(T * B, V, Oe, enc_tm, fc_w, A, b_sn=Ocat, b_sk=1, bias=fc_b, flags=GEMM_GELU_A)
+    max_out = T * max_iters
+    tokens = torch.full((B, max_out), blank, device=enc_tm.device, dtype=torch.int64)
+    ntok = torch.zeros(B, device=enc_tm.device, dtype=torch.int32)
+    d = _lib.DecodeDesc()
+    d.T, d.B, d.V, d.Hp, d.O, d.L, d.cell = T, B, V, Hp, Od, L, cell
+    d.blank, d.max_iters, d.max_out = blank, max_iters, max_out
+    d.A, d.t_lens, d.emb = _addr(A), _addr(t_lens), _addr(emb_w)
+    keep = []
+    for l in range(L):
+        w = [_f32c(t, "prediction-net weight") for t in rnn_weights[4 * l:4 * l + 4]]
+        keep.append(w)
+        d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_addr(t) for t in w)
+    d.w_o, d.b_o = _addr(out_w), _addr(out_b)
+    d.w_d, d.ld_d = _addr(fc_w, Oe), Ocat
+    d.tokens, d.ntok = _addr(tokens), _addr(ntok)
+    check(_lib.lib().rnnt_hip_greedy_decode(C.byref(d), _stream()), "rnnt_hip_greedy_decode")
+    return tokens, ntok
