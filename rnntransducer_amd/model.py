@@ -9,8 +9,11 @@ Differences, all inside the hot path:
   * `training_step` runs the FUSED joint + RNN-T loss (`JointNet.loss`): the (B,T,U+1,V) logits tensor the
     reference builds at model.py:56 is never materialised.  `forward()` still returns it on request.
   * blank/pad id comes from `args.blank_token_id` / `prednet_params["pad_token_id"]` (default 0, as in the shipped
-    config.json:37,40) instead of loading a tokenizer (model.py:24-26): tokenizer, WER/CER and decoding are
-    validation-side and out of scope.
+    config.json:37,40) instead of loading a tokenizer (model.py:24-26): tokenizer and WER/CER are validation-side
+    and out of scope.
+  * `validation_step` stays on the GPU (the reference moves the module to the CPU at model.py:65-72 because its
+    decode is a host loop): fused loss + on-device greedy search; it returns token ids, and texts only if a
+    tokenizer object was attached as `self.tokenizer`.
 """
 from argparse import Namespace
 
@@ -67,6 +70,28 @@ class RNNTransducer(_Base):
         if pl is not None and getattr(self, "_trainer", None) is not None:
             self.log("train_loss", loss, sync_dist=True)
         return {"loss": loss}
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """model.py:62-79: loss + greedy search (max 3 symbols per frame).  `pred_tokens` is a list of B 1-D LongTensors
+        (each what the reference's batch-1 recognize_greedy returns for that utterance), `label_tokens` the un-padded targets."""
+        input_audios, audio_lengths, tensor_audio_lengths, input_texts, text_lengths, targets, target_lengths = batch
+        nll = self.jointnet.loss(input_audios, tensor_audio_lengths, input_texts, targets, target_lengths, self.blank_token_id)
+        was_training = self.jointnet.training
+        self.jointnet.eval()
+        try:
+            pred = self.jointnet.recognize_greedy(input_audios, tensor_audio_lengths, self.blank_token_id, 3)
+        finally:
+            self.jointnet.train(was_training)
+        pred = [p for p in pred] if isinstance(pred, list) else [pred[0]]
+        u = target_lengths.tolist() if isinstance(target_lengths, torch.Tensor) else list(target_lengths)
+        labels = [targets[b, :u[b]].long() for b in range(targets.size(0))]
+        out = {"loss": nll.mean(), "pred_tokens": pred, "label_tokens": labels}
+        tok = getattr(self, "tokenizer", None)
+        if tok is not None:
+            out["pred_texts"] = tok.batch_decode([p.tolist() for p in pred])
+            out["label_texts"] = tok.batch_decode([l.tolist() for l in labels])
+        return out
 
     def configure_optimizers(self):
         group = [{"params": [p for p in self.parameters()], "name": "OneCycleLR"}]

@@ -83,3 +83,59 @@ def test_greedy_max_iters_one_and_training_mode_guard():
     got = net.eval().recognize_greedy(audios.cuda(), lens, 0, 1)
     assert [x.tolist() for x in got] == ora.recognize_greedy(audios, lens, 0, 1)
     assert all(len(x) <= t for x, t in zip(got, lens))
+
+
+def test_validation_step_after_overfitting_one_batch_recovers_labels():
+    """End to end through the drop-in surface: training_step (fused loss) + FlatAdamW overfit one small batch, then
+    validation_step's on-device greedy search reads (most of) the labels back and agrees token for token with the oracle's
+    search on the trained weights (targets have no immediate repeats, which the search collapses: transducer.py:132-133)."""
+    from argparse import Namespace
+    from rnntransducer_amd import RNNTransducer
+    from rnntransducer_amd.data import synthetic_batch
+    tn = dict(input_size=80, hidden_size=128, output_size=128, num_layers=1, dropout=0.0, bidirectional=True)
+    pn = dict(embedding_size=72, pad_token_id=0, hidden_size=128, output_size=128, num_layers=1, dropout=0.0)
+    args = Namespace(learning_rate=4e-3, weight_decay=0.0, warmup_ratio=0.1, final_div_factor=10.0, total_steps=400,
+                     move_metrics_to_cpu=False)
+    torch.manual_seed(1)
+    model = RNNTransducer(pn, tn, dict(num_classes=72), args).cuda().train()
+    batch = list(synthetic_batch(2, 60, 12, 72, device="cuda", seed=4))
+    targets = batch[5].clone()
+    for b in range(targets.size(0)):  # remove immediate repeats, keep ids in [1, V)
+        for u in range(1, targets.size(1)):
+            if targets[b, u] == targets[b, u - 1]:
+                targets[b, u] = targets[b, u] % 71 + 1
+    batch[5] = targets
+    batch[3] = torch.cat([torch.zeros_like(batch[3][:, :1]), targets.long()], 1)
+    # make the "audio" alignable (pure noise trains to a diffuse alignment that no greedy search can follow): label u is
+    # announced on frame 5u+2 by a fixed random code vector of its id
+    codes = torch.randn(72, 80, generator=torch.Generator().manual_seed(8)).cuda()
+    audio = 0.1 * batch[0]
+    for b in range(targets.size(0)):
+        for u in range(targets.size(1)):
+            audio[b, 5 * u + 2] = 2.0 * codes[int(targets[b, u])]
+    batch[0] = audio.contiguous()
+    cfg = model.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    for step in range(400):
+        opt.zero_grad()
+        loss = model.training_step(tuple(batch), step)["loss"]
+        loss.backward()
+        opt.step()
+        sched.step()
+    assert loss.item() < 0.05, loss.item()
+    out = model.validation_step(tuple(batch), 0)
+    assert model.jointnet.training  # mode restored
+    assert out["loss"].item() < 0.05
+    from oracle.rnnt_oracle import OracleJointNet
+    labels = [l.tolist() for l in out["label_tokens"]]
+    # a greedy search need not follow the most probable alignment even at P(y|x) > 0.95 (emission mass may be spread
+    # below 0.5 per frame), so the read-back check is: an ordered subsequence of the labels, at least half of them
+    for pred, label in zip(out["pred_tokens"], labels):
+        it = iter(label)
+        assert all(tok in it for tok in pred.tolist()), (pred.tolist(), label)
+        assert len(pred) >= len(label) // 2
+    ora = OracleJointNet(tn, pn, 72).eval()
+    ora.load_state_dict({k[len("jointnet."):]: v.cpu() for k, v in model.state_dict().items()})
+    want, margin = ora.recognize_greedy(batch[0].cpu(), batch[1], 0, 3, return_margin=True)
+    if margin >= 1e-4:
+        assert [p.tolist() for p in out["pred_tokens"]] == want
