@@ -68,11 +68,18 @@ int rnnt_hip_prof_collect(double* ms, double* work, int64_t* count, int nkinds);
  *   B(k,n) = B[n*b_sn + k*b_sk]                 exactly one of b_sn, b_sk is 1
  *   C(m,n) = C[(m / c_div)*c_so + (m % c_div)*c_si + n]
  * flags: see RNNT_GEMM_*.
+ *
+ * Arithmetic: inputs, outputs and accumulators are fp32 in every mode.  Default (RNNT_GEMM_MODE unset or "bf16x6"):
+ * each fp32 operand is split EXACTLY into three bf16 pieces and the six piece products of fp32 weight run on
+ * v_mfma_f32_32x32x16_bf16 (error per product <= ~3 * 2^-24, the order of fp32 rounding itself).  "f32": the
+ * f32-input MFMA (exact fp32 fma chain).  "bf16x3": first-order pieces only (~2^-16 per product), opt-in.
  * ---------------------------------------------------------------------------------------------- */
 #define RNNT_GEMM_GELU_A 1u      /* apply gelu_tanh to A elements on load  (transducer.py:38,68)   */
 #define RNNT_GEMM_GELU_B 2u      /* apply gelu_tanh to B elements on load                          */
 #define RNNT_GEMM_ACCUM 4u       /* C += result                                                    */
 #define RNNT_GEMM_MUL_DGELU 8u   /* C = result * gelu_tanh'(aux(m,n)), aux laid out like C          */
+#define RNNT_GEMM_EXACT_F32 16u  /* multiply on v_mfma_f32_32x32x2_f32 (bit-exact fp32 fma chains) even when the
+                                  * library default is the split-bf16 form (see below)                      */
 
 typedef struct rnnt_gemm_desc {
   int64_t M, N, K;

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librnnt_hip.so")
 
-GEMM_GELU_A, GEMM_GELU_B, GEMM_ACCUM, GEMM_MUL_DGELU = 1, 2, 4, 8
+GEMM_GELU_A, GEMM_GELU_B, GEMM_ACCUM, GEMM_MUL_DGELU, GEMM_EXACT_F32 = 1, 2, 4, 8, 16
 CELL_LSTM, CELL_GRU, CELL_RNN_TANH, CELL_RNN_RELU = 0, 1, 2, 3
 
 c_f32p = C.c_void_p

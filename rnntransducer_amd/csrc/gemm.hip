@@ -109,31 +109,10 @@ struct TileIO {
   }
 };
 
-// NW = 32-wide N tiles per wave: 2 -> 128x128 block tile, 4 -> 128x256 (each wave 64x128: 8 MFMAs per operand fetch,
-// 25% fewer operand bytes per FLOP; used when N is wide enough)
-template <bool A_KC, bool B_KC, bool VEC4, int NW>
-__global__ void __launch_bounds__(256, (NW == 4 ? 2 : 3)) gemm_f32_kernel(const GemmK p) {
-  constexpr int BN = 64 * NW, LDB = BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
-
+// operand-row pointers / bases of this workgroup's A and B tiles (shared by the fp32 and the split-bf16 kernels)
+template <bool A_KC, bool B_KC, int BN, typename TA, typename TB>
+__device__ __forceinline__ void setup_io(TA& ta, TB& tb, const GemmK& p, int m0, int n0) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // tile coordinates: consecutive block ids walk down M first so that the (usually small) B panel and a
-  // band of A stay in the XCD's L2; ids are dealt round-robin over 8 XCDs, so regroup them (bijective map).
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
-  const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
-
-  TileIO<A_KC, VEC4, BM> ta;
-  TileIO<B_KC, VEC4, BN> tb;
   ta.K = tb.K = p.K;
   ta.gelu = (p.flags & RNNT_GEMM_GELU_A) != 0;
   tb.gelu = (p.flags & RNNT_GEMM_GELU_B) != 0;
@@ -166,6 +145,83 @@ __global__ void __launch_bounds__(256, (NW == 4 ? 2 : 3)) gemm_f32_kernel(const 
     tb.r0 = n0;
     tb.R = p.N;
   }
+}
+
+// C/D map of the 32x32 MFMAs (f32 and bf16 forms alike): col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+template <int NW>
+__device__ __forceinline__ void epilogue(const GemmK& p, const f32x16 (&acc)[2][NW], int m0, int n0, int wm, int wn, int lane) {
+  if (p.splits > 1) {
+    float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const int n = n0 + wn * (32 * NW) + j * 32 + (lane & 31);
+          if (n < p.N) slab[(long)m * p.N + n] = acc[i][j][v];
+        }
+      }
+    return;
+  }
+  const bool accum = (p.flags & RNNT_GEMM_ACCUM) != 0, dgelu = (p.flags & RNNT_GEMM_MUL_DGELU) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+      if (m >= p.M) continue;
+      const long rowoff = (long)(m / p.c_div) * p.c_so + (long)(m % p.c_div) * p.c_si;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int n = n0 + wn * (32 * NW) + j * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        float val = acc[i][j][v];
+        if (p.bias) val += p.bias[n];
+        const long off = rowoff + n;
+        if (dgelu) val *= dgelu_tanh(p.aux[off]);
+        if (accum) val += p.C[off];
+        p.C[off] = val;
+      }
+    }
+  }
+}
+
+// bijective regrouping of block ids so that the tiles one XCD works on are neighbours (ids are dealt round-robin
+// over the 8 XCDs); consecutive regrouped ids walk down M first
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+// NW = 32-wide N tiles per wave: 2 -> 128x128 block tile, 4 -> 128x256 (each wave 64x128: 8 MFMAs per operand fetch,
+// 25% fewer operand bytes per FLOP; used when N is wide enough)
+template <bool A_KC, bool B_KC, bool VEC4, int NW>
+__global__ void __launch_bounds__(256, (NW == 4 ? 2 : 3)) gemm_f32_kernel(const GemmK p) {
+  constexpr int BN = 64 * NW, LDB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // tile coordinates: consecutive block ids walk down M first so that the (usually small) B panel and a
+  // band of A stay in the XCD's L2; ids are dealt round-robin over 8 XCDs, so regroup them (bijective map).
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
+
+  TileIO<A_KC, VEC4, BM> ta;
+  TileIO<B_KC, VEC4, BN> tb;
+  setup_io<A_KC, B_KC, BN>(ta, tb, p, m0, n0);
 
   f32x16 acc[2][NW];
 #pragma unroll
@@ -234,44 +290,273 @@ __global__ void __launch_bounds__(256, (NW == 4 ? 2 : 3)) gemm_f32_kernel(const 
     __syncthreads();
   }
 
-  // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
-  if (p.splits > 1) {
-    float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
+  epilogue<NW>(p, acc, m0, n0, wm, wn, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores by operand splitting.
+//
+// x = x0 + x1 + x2 EXACTLY, each piece 8 significant bits (truncation split: x0 = x & 0xffff0000, r = x - x0 is exact,
+// x1 = r & 0xffff0000, x2 = r - x1 has <= 8 bits left), so every piece is a bf16 and every piece product is exact in the
+// fp32 accumulator.  a.b = sum_{i+j<=2} a_i b_j + O(2^-24 |a||b|): six v_mfma_f32_32x32x16_bf16 per 32x32x16 block
+// (192 MFMA cycles) against eight v_mfma_f32_32x32x2_f32 (512): the same fp32 inputs, outputs, accumulators and
+// error order as the exact-fp32 kernel above at 2.67x its matrix-core rate.  NPROD = 3 keeps only i+j<=1 (error 2^-16,
+// round-to-nearest second piece): opt-in.
+//
+// LDS: one [rows][16 k] bf16 image per piece; row r at byte (r&3)*X + (r>>2)*48 with X = 64 (mod 256): the ds_read_b128
+// operand fetch (32 consecutive rows per half-wave) is conflict-free, and both producers - a thread holding 4 k of one
+// row (k-contiguous operand) or 2-4 k of 4 neighbouring rows (row-contiguous operand) - store with at most 2-4-way
+// conflicts, which ds_write_b32/b64 absorb in their issue time.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int ROWS, int BKS>
+struct PlaneImg {
+  static constexpr int RS = 2 * BKS + 16;           // bytes per row: payload + 16 pad (odd number of 16-B slots)
+  static constexpr int X = (ROWS / 4) * RS + 64;    // distance between the four row classes r&3
+  static constexpr int BYTES = 4 * X;
+  static_assert(((ROWS / 4) * RS) % 256 == 0, "class distance must be 64 (mod 256)");
+  static __device__ __forceinline__ int off(int r) { return (r & 3) * X + (r >> 2) * RS; }
+};
+
+// (even-k, odd-k) pair of fp32 -> one packed dword (2 x bf16) per piece
+template <int NPL>
+__device__ __forceinline__ void split_pair(float xe, float xo, unsigned (&pk)[NPL]) {
+  constexpr unsigned SEL = 0x07060302u;  // D = {S1.b2, S1.b3, S0.b2, S0.b3}: upper halves of (even, odd)
+  const unsigned ue = __float_as_uint(xe), uo = __float_as_uint(xo);
+  pk[0] = __builtin_amdgcn_perm(uo, ue, SEL);
+  const float re = xe - __uint_as_float(ue & 0xffff0000u), ro = xo - __uint_as_float(uo & 0xffff0000u);
+  unsigned ure = __float_as_uint(re), uro = __float_as_uint(ro);
+  if constexpr (NPL == 2) {  // last piece kept: round it to nearest instead of truncating
+    ure += 0x8000u;
+    uro += 0x8000u;
+  }
+  pk[1] = __builtin_amdgcn_perm(uro, ure, SEL);
+  if constexpr (NPL == 3) {
+    const float le = re - __uint_as_float(ure & 0xffff0000u), lo = ro - __uint_as_float(uro & 0xffff0000u);
+    pk[2] = __builtin_amdgcn_perm(__float_as_uint(lo), __float_as_uint(le), SEL);
+  }
+}
+
+// Global fp32 -> registers -> NPL bf16 piece images in LDS, for a (ROWS) x (BKS k) operand tile and 256 threads.
+// KC (k-contiguous rows): BKS/4 threads per row, each one float4 = 4 consecutive k; with BKS = 32 a row's 128 bytes are
+// one whole cache line.  !KC (row-contiguous): a thread takes 4 neighbouring rows x NP CONSECUTIVE k.
+template <bool KC, bool VEC4, int ROWS, int BKS, int NPL>
+struct SplitIO {
+  static constexpr int NP = ROWS * BKS / 1024;      // float4 per thread per K-tile
+  static constexpr int TPK = BKS / 4;               // KC: threads per row
+  static constexpr int RPP = 256 / TPK;             // KC: rows per pass
+  static constexpr int TPR = ROWS / 4;              // !KC: threads per k-row
+  static_assert(NP == 2 || NP == 4, "tile shape");
+  using Img = PlaneImg<ROWS, BKS>;
+  f32x4 v[NP];
+  const float* rowptr[NP];
+  const float* base;
+  long sk;
+  int r0, R, K;
+  bool gelu;
+
+  __device__ __forceinline__ void load(int k0) {
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int p = 0; p < NP; ++p) {
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (KC) {
+        const int k = k0 + 4 * (tid % TPK);
+        const float* src = rowptr[p];
+        if (src != nullptr) {
+          if (VEC4 && k + 3 < K) {
+            x = *reinterpret_cast<const f32x4*>(src + k);
+          } else {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-        if (m >= p.M) continue;
+            for (int e = 0; e < 4; ++e)
+              if (k + e < K) x[e] = src[k + e];
+          }
+        }
+      } else {
+        const int k = k0 + (tid / TPR) * NP + p;
+        const int r = r0 + 4 * (tid % TPR);
+        if (k < K) {
+          const float* src = base + (long)k * sk + r;
+          if (VEC4 && r + 3 < R) {
+            x = *reinterpret_cast<const f32x4*>(src);
+          } else {
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-          const int n = n0 + wn * (32 * NW) + j * 32 + (lane & 31);
-          if (n < p.N) slab[(long)m * p.N + n] = acc[i][j][v];
+            for (int e = 0; e < 4; ++e)
+              if (r + e < R) x[e] = src[e];
+          }
         }
       }
-    return;
+      if (gelu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = gelu_tanh(x[e]);
+      }
+      v[p] = x;
+    }
   }
-  const bool accum = (p.flags & RNNT_GEMM_ACCUM) != 0, dgelu = (p.flags & RNNT_GEMM_MUL_DGELU) != 0;
+
+  __device__ __forceinline__ void store(char* S) const {
+    const int tid = threadIdx.x;
+    if constexpr (KC) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+      for (int p = 0; p < NP; ++p) {
+        unsigned lo[NPL], hi[NPL];
+        split_pair<NPL>(v[p][0], v[p][1], lo);
+        split_pair<NPL>(v[p][2], v[p][3], hi);
+        char* dst = S + Img::off(tid / TPK + RPP * p) + 8 * (tid % TPK);
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-      if (m >= p.M) continue;
-      const long rowoff = (long)(m / p.c_div) * p.c_so + (long)(m % p.c_div) * p.c_si;
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * Img::BYTES) = u32x2{lo[pl], hi[pl]};
+      }
+    } else {
+      const int kb = (tid / TPR) * NP;
 #pragma unroll
-      for (int j = 0; j < NW; ++j) {
-        const int n = n0 + wn * (32 * NW) + j * 32 + (lane & 31);
-        if (n >= p.N) continue;
-        float val = acc[i][j][v];
-        if (p.bias) val += p.bias[n];
-        const long off = rowoff + n;
-        if (dgelu) val *= dgelu_tanh(p.aux[off]);
-        if (accum) val += p.C[off];
-        p.C[off] = val;
+      for (int e = 0; e < 4; ++e) {
+        char* dst = S + Img::off(4 * (tid % TPR) + e) + 2 * kb;
+        unsigned lo[NPL];
+        split_pair<NPL>(v[0][e], v[1][e], lo);
+        if constexpr (NP == 2) {
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<unsigned*>(dst + pl * Img::BYTES) = lo[pl];
+        } else {
+          unsigned hi[NPL];
+          split_pair<NPL>(v[2][e], v[3][e], hi);
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * Img::BYTES) = u32x2{lo[pl], hi[pl]};
+        }
       }
     }
   }
+};
+
+// row pointers of the split kernels' k-contiguous operands (RPP rows per pass instead of 64)
+template <bool A_KC, bool B_KC, typename TA, typename TB>
+__device__ __forceinline__ void setup_split_io(TA& ta, TB& tb, const GemmK& p, int m0, int n0) {
+  const int tid = threadIdx.x;
+  ta.K = tb.K = p.K;
+  ta.gelu = (p.flags & RNNT_GEMM_GELU_A) != 0;
+  tb.gelu = (p.flags & RNNT_GEMM_GELU_B) != 0;
+  if constexpr (A_KC) {
+#pragma unroll
+    for (int q = 0; q < TA::NP; ++q) {
+      const int m = m0 + tid / TA::TPK + TA::RPP * q;
+      if (m < p.M) {
+        long off = p.a_rowidx ? p.a_rowidx[m] * p.a_si : (long)(m / p.a_div) * p.a_so + (long)(m % p.a_div) * p.a_si;
+        ta.rowptr[q] = p.A + off;
+      } else {
+        ta.rowptr[q] = nullptr;
+      }
+    }
+  } else {
+    ta.base = p.A;
+    ta.sk = p.a_sk;
+    ta.r0 = m0;
+    ta.R = p.M;
+  }
+  if constexpr (B_KC) {
+#pragma unroll
+    for (int q = 0; q < TB::NP; ++q) {
+      const int n = n0 + tid / TB::TPK + TB::RPP * q;
+      tb.rowptr[q] = n < p.N ? p.B + (long)n * p.b_sn : nullptr;
+    }
+  } else {
+    tb.base = p.B;
+    tb.sk = p.b_sk;
+    tb.r0 = n0;
+    tb.R = p.N;
+  }
+}
+
+template <bool A_KC, bool B_KC, bool VEC4, int NW, int NPROD, int BKS>
+__global__ void __launch_bounds__(256, 2) gemm_bf16s_kernel(const GemmK p) {
+  constexpr int BN = 64 * NW;
+  constexpr int NPL = NPROD == 6 ? 3 : 2;
+  using IA = PlaneImg<BM, BKS>;
+  using IB = PlaneImg<BN, BKS>;
+  __shared__ __attribute__((aligned(16))) char As[NPL * IA::BYTES];
+  __shared__ __attribute__((aligned(16))) char Bs[NPL * IB::BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
+
+  SplitIO<A_KC, VEC4, BM, BKS, NPL> ta;
+  SplitIO<B_KC, VEC4, BN, BKS, NPL> tb;
+  setup_split_io<A_KC, B_KC>(ta, tb, p, m0, n0);
+
+  f32x16 acc[2][NW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  ta.K = tb.K = kend;
+  const int nk = (kend - kbeg + BKS - 1) / BKS;
+  ta.load(kbeg);
+  tb.load(kbeg);
+
+  // MFMA operand fetch: lane -> row (lane&31) of a 32-row block, k 8*(lane>>5) .. +7 (16 bytes) of a 16-k step
+  const char* ard[2];
+  const char* brd[NW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ard[i] = As + IA::off(wm * 64 + i * 32 + (lane & 31)) + 16 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < NW; ++j) brd[j] = Bs + IB::off(wn * (32 * NW) + j * 32 + (lane & 31)) + 16 * (lane >> 5);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt) __syncthreads();  // every wave is done reading the previous K-tile's images
+    ta.store(As);
+    tb.store(Bs);
+    __syncthreads();
+    ta.load(kbeg + (kt + 1) * BKS);  // lands behind the MFMAs; past the last tile everything is predicated off
+    tb.load(kbeg + (kt + 1) * BKS);
+#pragma unroll
+    for (int ks = 0; ks < BKS / 16; ++ks) {
+      bf16x8 af[2][NPL], bf[NW][NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ard[i] + pl * IA::BYTES + 32 * ks));
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+          bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(brd[j] + pl * IB::BYTES + 32 * ks));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          // smallest terms first
+          if constexpr (NPROD == 6) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  epilogue<NW>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// how the GEMMs multiply: 6 = split-bf16 with all terms of fp32 weight (default), 3 = split-bf16 first-order only,
+// 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fma chains).  RNNT_GEMM_MODE = bf16x6 | bf16x3 | f32.
+inline int gemm_mode() {
+  const char* e = getenv("RNNT_GEMM_MODE");
+  if (e == nullptr || e[0] == 0) return 6;
+  if (e[0] == 'f') return 0;
+  return (e[0] == 'b' && e[4] == 'x' && e[5] == '3') ? 3 : 6;
 }
 
 // fixed-order sum of the split-K slabs + the epilogue the single-pass kernel would have applied
@@ -304,7 +589,9 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 extern "C" size_t rnnt_hip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   // enough for the split count rnnt_hip_gemm_f32 would pick; 0 when it would not split
   if (M <= 0 || N <= 0 || K < 8 * rnnt::BK) return 0;
-  const long tiles = rnnt::ceil_div(M, rnnt::BM) * rnnt::ceil_div(N, rnnt::pick_bn(M, N));
+  const int mode = rnnt::gemm_mode();
+  const int bn = (mode && getenv("RNNT_GEMM_BK32")) ? 128 : rnnt::pick_bn(M, N);
+  const long tiles = rnnt::ceil_div(M, rnnt::BM) * rnnt::ceil_div(N, bn);
   if (tiles >= 512) return 0;
   long want = rnnt::ceil_div(1024, tiles);
   const long by_k = K / (8 * rnnt::BK);
@@ -346,7 +633,9 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   if (b_kc) vec = vec && (d->b_sn % 4 == 0);
   else vec = vec && (d->b_sk % 4 == 0);
 
-  const int bn = pick_bn(d->M, d->N);
+  const int mode = (d->flags & RNNT_GEMM_EXACT_F32) ? 0 : gemm_mode();
+  const int bks = (mode && getenv("RNNT_GEMM_BK32")) ? 32 : BK;  // K-tile depth 32 (128x128 tiles only): measured slower
+  const int bn = (mode && bks == 32) ? 128 : pick_bn(d->M, d->N);
   const int tiles = (int)(ceil_div(d->M, BM) * ceil_div(d->N, bn));
   // split-K when the output has too few tiles to fill 256 CUs and K is deep (weight-gradient GEMMs):
   // partial slabs in the caller's workspace, summed in fixed order (bitwise reproducible; no float atomics)
@@ -360,22 +649,31 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
     if (want > 64) want = 64;
     if (want >= 2) splits = (int)want;
   }
-  k.kchunk = splits > 1 ? (int)(ceil_div(ceil_div(d->K, splits), BK) * BK) : (int)(d->K > 0 ? d->K : 1);
+  k.kchunk = splits > 1 ? (int)(ceil_div(ceil_div(d->K, splits), bks) * bks) : (int)(d->K > 0 ? d->K : 1);
   if (splits > 1) splits = (int)ceil_div(d->K, k.kchunk);
   k.splits = splits;
   k.slab = (float*)d->workspace;
   dim3 grid(tiles, splits), block(256);
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(RNNT_K_GEMM, 2.0 * (double)d->M * (double)d->N * (double)d->K, s);
-#define LAUNCH(AK, BKC, V)                                                                      \
-  do {                                                                                          \
-    if (bn == 256) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, V, 4>), grid, block, 0, s, k);  \
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, V, 2>), grid, block, 0, s, k);            \
+#define LAUNCH_K(KERNEL4, KERNEL2)                                        \
+  do {                                                                    \
+    if (bn == 256) hipLaunchKernelGGL((KERNEL4), grid, block, 0, s, k);   \
+    else hipLaunchKernelGGL((KERNEL2), grid, block, 0, s, k);             \
+  } while (0)
+#define LAUNCH(AK, BKC, V)                                                                                              \
+  do {                                                                                                                  \
+    if (mode == 6 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 6, 32>), grid, block, 0, s, k);    \
+    else if (mode == 3 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 3, 32>), grid, block, 0, s, k); \
+    else if (mode == 6) LAUNCH_K((gemm_bf16s_kernel<AK, BKC, V, 4, 6, 16>), (gemm_bf16s_kernel<AK, BKC, V, 2, 6, 16>)); \
+    else if (mode == 3) LAUNCH_K((gemm_bf16s_kernel<AK, BKC, V, 4, 3, 16>), (gemm_bf16s_kernel<AK, BKC, V, 2, 3, 16>)); \
+    else LAUNCH_K((gemm_f32_kernel<AK, BKC, V, 4>), (gemm_f32_kernel<AK, BKC, V, 2>));                                  \
   } while (0)
   if (a_kc && b_kc) { if (vec) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
   else if (a_kc && !b_kc) { if (vec) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
   else if (!a_kc && b_kc) { if (vec) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
   else { if (vec) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+#undef LAUNCH_K
 #undef LAUNCH
   RNNT_CHECK_LAUNCH();
   if (splits > 1) {

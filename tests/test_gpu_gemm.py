@@ -1,4 +1,8 @@
-"""rnnt_hip_gemm_f32 (f32-input MFMA) vs a float64 CPU product: every operand map the hot path uses."""
+"""rnnt_hip_gemm_f32 vs a float64 CPU product: every operand map the hot path uses, in the library's default arithmetic
+(fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulate) and, in
+test_gemm_arithmetic_modes, in the exact-fp32-MFMA and first-order-split modes as well."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -116,3 +120,66 @@ def test_colsum(M, N):
     out = colsum(x.cuda(), M, N)
     ref = x.double().sum(0)
     assert (out.double().cpu() - ref).abs().max().item() < 1e-5 * max(1.0, x.abs().double().sum(0).max().item())
+
+
+@pytest.fixture
+def gemm_mode_env():
+    saved = os.environ.get("RNNT_GEMM_MODE")
+    yield
+    if saved is None:
+        os.environ.pop("RNNT_GEMM_MODE", None)
+    else:
+        os.environ["RNNT_GEMM_MODE"] = saved
+
+
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+def test_gemm_arithmetic_modes(gemm_mode_env, form):
+    """Error of each arithmetic mode against an fp64 product of the same fp32 inputs.  The default split-bf16 (6 products)
+    must be as accurate as the exact fp32 fma chain (measured: slightly better); the 3-product form is ~2^-16."""
+    from rnntransducer_amd._lib import GEMM_EXACT_F32
+    from rnntransducer_amd.ops import gemm
+    M, N, K = 384, 512, 2048
+    g = torch.Generator().manual_seed(77)
+    # wide dynamic range: magnitudes from 1e-6 to 1e3 so that piece exponents matter
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.empty(M, K).uniform_(-14, 7, generator=g))
+    W = torch.randn(N, K, generator=g) * torch.exp(torch.empty(N, K).uniform_(-14, 7, generator=g))
+    if form == "nt":
+        a, w, kw = A, W, {}
+    elif form == "nn":
+        a, w, kw = A, W.t().contiguous(), dict(b_sn=1, b_sk=N)
+    else:
+        a, w, kw = A.t().contiguous(), W.t().contiguous(), dict(a_mc=True, a_sk=M, b_sn=1, b_sk=N)
+    ref = A.double() @ W.double().T
+    scale = (A.abs().double() @ W.abs().double().T)
+
+    def run(mode, flags=0):
+        os.environ["RNNT_GEMM_MODE"] = mode
+        out = torch.full((M, N), float("nan"), device="cuda")
+        gemm(M, N, K, a.cuda(), w.cuda(), out, flags=flags, **kw)
+        return out.cpu()
+
+    outs = {m: run(m) for m in ("f32", "bf16x6", "bf16x3")}
+    err = {m: ((o.double() - ref).abs() / scale).max().item() for m, o in outs.items()}
+    assert err["f32"] < 2e-6 and err["bf16x6"] < 2e-6, err
+    assert err["bf16x6"] <= 1.5 * err["f32"], err
+    assert 1e-7 < err["bf16x3"] < 1e-4, err
+    # the per-call flag forces the exact-fp32 MFMA whatever the library default is
+    assert torch.equal(run("bf16x6", GEMM_EXACT_F32), outs["f32"])
+    assert torch.equal(run("", 0), outs["bf16x6"])  # unset / empty = the default
+
+
+def test_gemm_split_pieces_are_exact_on_hard_values(gemm_mode_env):
+    """Values whose bf16 pieces straddle exponents (1 + 2^-8 + 2^-16 patterns, negative, tiny, powers of two, all-ones
+    mantissas): one-term dot products must come out bit-exact, as an fp32 multiply gives them."""
+    from rnntransducer_amd.ops import gemm
+    os.environ["RNNT_GEMM_MODE"] = "bf16x6"
+    vals = torch.tensor([1.0, -1.0, 1.0 + 2 ** -8, 1.0 + 2 ** -16, 1.0 + 2 ** -23, 2.0 - 2 ** -23, -(2.0 - 2 ** -23), 3.0e-30, 7.0e20,
+                         0.1, -0.3, 65504.0, 2 ** -100, 1.0 + 2 ** -7 + 2 ** -15 + 2 ** -23, 0.0, 123456.789])
+    M = N = len(vals)
+    A = torch.zeros(M, 16)
+    A[:, 3] = vals               # a single non-zero k: the product is one multiplication, no summation error
+    W = torch.zeros(N, 16)
+    W[:, 3] = torch.tensor([1.0, 2.0, -4.0, 0.5, 2 ** -20, 2 ** 20, 1.0, -1.0, 8.0, 0.25, 1.0, 2.0, 1.0, -2.0, 1.0, 16.0])
+    out = torch.empty(M, N, device="cuda")
+    gemm(M, N, 16, A.cuda(), W.cuda(), out)
+    assert torch.equal(out.cpu(), A[:, 3:4] * W[:, 3:4].T)  # power-of-two multipliers: exact in fp32

@@ -1,4 +1,5 @@
-"""Times the three dominant GEMM shapes of BASELINE config 2 through the C ABI (fp32-input MFMA kernel).
+"""Times the dominant GEMM shapes of BASELINE config 2 through the C ABI in each arithmetic mode (RNNT_GEMM_MODE =
+bf16x6 [default] | bf16x3 | f32) and measures each mode's error against an fp64 product of the same fp32 inputs.
    python tools/gemm_bench.py [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,15 +23,38 @@ cases = {
     "TN  dG^T.h  (M=2048,N=512,K=32000)   dW_hh (split-K)": lambda: gemm(2048, 512, M, dg, x, out_tn, a_mc=True, a_sk=N, b_sn=1, b_sk=K, split_k=True),
 }
 flops = {0: 2.0 * M * N * K, 1: 2.0 * M * N * K, 2: 2.0 * M * N * K, 3: 2.0 * 2048 * 512 * M}
-for i, (name, fn) in enumerate(cases.items()):
-    for _ in range(2):
-        fn()
+rows = torch.arange(0, M, 125, device=dev)  # 256 sample rows
+
+
+def errors():
+    """(max, rms) error relative to the rms magnitude of the exact result, per GEMM form"""
+    out = []
+    ref = x[rows].double() @ w.double().t()
+    out.append(("NT", out_nt[rows].double() - ref, ref))
+    ref = dg[rows].double() @ w.double()
+    out.append(("NN", out_nn[rows].double() - ref, ref))
+    cols = torch.arange(0, N, 16, device=dev)
+    ref = dg[:, cols].double().t() @ x.double()
+    out.append(("TN", out_tn[cols].double() - ref, ref))
+    return "  ".join(f"{n}: max {float(d.abs().max() / r.pow(2).mean().sqrt()):.2e} rms {float(d.pow(2).mean().sqrt() / r.pow(2).mean().sqrt()):.2e}"
+                     for n, d, r in out)
+
+
+for mode in ("bf16x6", "bf16x3", "f32"):
+    os.environ["RNNT_GEMM_MODE"] = mode
+    print(f"--- RNNT_GEMM_MODE={mode}")
+    for i, (name, fn) in enumerate(cases.items()):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        print(f"{name:62s} {ms:7.3f} ms  {flops[i] / ms / 1e9:7.1f} TFLOP/s (fp32-equivalent)")
+    list(cases.values())[2]()  # out_tn holds the full dW_ih product again
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / reps
-    print(f"{name:62s} {ms:7.3f} ms  {flops[i] / ms / 1e9:7.1f} TFLOP/s")
+    print("error vs fp64 / rms(|exact|):  " + errors())
