@@ -469,7 +469,7 @@ __device__ __forceinline__ void setup_split_io(TA& ta, TB& tb, const GemmK& p, i
   }
 }
 
-template <bool A_KC, bool B_KC, bool VEC4, int NW, int NPROD, int BKS>
+template <bool A_KC, bool B_KC, bool VEC4, int NW, int NPROD, int BKS, bool DBG = false>
 __global__ void __launch_bounds__(256, 2) gemm_bf16s_kernel(const GemmK p) {
   constexpr int BN = 64 * NW;
   constexpr int NPL = NPROD == 6 ? 3 : 2;
@@ -512,13 +512,30 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16s_kernel(const GemmK p) {
 #pragma unroll
   for (int j = 0; j < NW; ++j) brd[j] = Bs + IB::off(wn * (32 * NW) + j * 32 + (lane & 31)) + 16 * (lane >> 5);
 
+  long ph[6] = {0, 0, 0, 0, 0, 0};  // DBG: cycles in barrier-1 | vmcnt wait | split+store | barrier-2 | load issue | ds_read+MFMA
   for (int kt = 0; kt < nk; ++kt) {
+    long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    if (DBG) c0 = clock64();
     if (kt) __syncthreads();  // every wave is done reading the previous K-tile's images
+    if (DBG) {
+      c1 = clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      c2 = clock64();
+    }
     ta.store(As);
     tb.store(Bs);
+    if (DBG) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      c3 = clock64();
+    }
     __syncthreads();
+    if (DBG) c4 = clock64();
     ta.load(kbeg + (kt + 1) * BKS);  // lands behind the MFMAs; past the last tile everything is predicated off
     tb.load(kbeg + (kt + 1) * BKS);
+    if (DBG) {
+      c5 = clock64();
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int ks = 0; ks < BKS / 16; ++ks) {
       bf16x8 af[2][NPL], bf[NW][NPL];
@@ -546,6 +563,18 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16s_kernel(const GemmK p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
         }
     }
+    if (DBG) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][NW - 1][15]));  // the last MFMAs have retired
+      const long c6 = clock64();
+      ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3; ph[4] += c5 - c4; ph[5] += c6 - c5;
+    }
+  }
+  if (DBG && lane == 0 && p.slab != nullptr && blockIdx.x % 64 == 0 && blockIdx.x / 64 < 32) {
+    long* out = reinterpret_cast<long*>(p.slab) + ((blockIdx.x / 64) * 4 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out[i] = ph[i];
+    out[6] = nk;
   }
   epilogue<NW>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -663,7 +692,9 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   } while (0)
 #define LAUNCH(AK, BKC, V)                                                                                              \
   do {                                                                                                                  \
-    if (mode == 6 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 6, 32>), grid, block, 0, s, k);    \
+    if (mode == 6 && bks == 16 && bn == 256 && splits == 1 && d->workspace && getenv("RNNT_GEMM_DBG"))                  \
+      hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 4, 6, 16, true>), grid, block, 0, s, k);                        \
+    else if (mode == 6 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 6, 32>), grid, block, 0, s, k);    \
     else if (mode == 3 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 3, 32>), grid, block, 0, s, k); \
     else if (mode == 6) LAUNCH_K((gemm_bf16s_kernel<AK, BKC, V, 4, 6, 16>), (gemm_bf16s_kernel<AK, BKC, V, 2, 6, 16>)); \
     else if (mode == 3) LAUNCH_K((gemm_bf16s_kernel<AK, BKC, V, 4, 3, 16>), (gemm_bf16s_kernel<AK, BKC, V, 2, 3, 16>)); \
