@@ -71,5 +71,41 @@ __device__ __forceinline__ float tanh_hw(float x) { return 1.0f - 2.0f * __frcp_
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Exact fp32 -> bf16 piece split (gemm.hip, lstm.hip): x = x0 + x1 + x2 with x0 = x & 0xffff0000, r = x - x0 (exact),
+// x1 = r & 0xffff0000, x2 = r - x1 (<= 8 significant bits left): every piece is a bf16 and piece products are exact in an
+// fp32 accumulator, so sum_{i+j<=2} a_i b_j reproduces the fp32 product to O(2^-24).
+// (even-k, odd-k) pair of fp32 -> one packed dword (2 x bf16) per piece
+template <int NPL>
+__device__ __forceinline__ void split_pair(float xe, float xo, unsigned (&pk)[NPL]) {
+  constexpr unsigned SEL = 0x07060302u;  // D = {S1.b2, S1.b3, S0.b2, S0.b3}: upper halves of (even, odd)
+  const unsigned ue = __float_as_uint(xe), uo = __float_as_uint(xo);
+  pk[0] = __builtin_amdgcn_perm(uo, ue, SEL);
+  const float re = xe - __uint_as_float(ue & 0xffff0000u), ro = xo - __uint_as_float(uo & 0xffff0000u);
+  unsigned ure = __float_as_uint(re), uro = __float_as_uint(ro);
+  if constexpr (NPL == 2) {  // last piece kept: round it to nearest instead of truncating
+    ure += 0x8000u;
+    uro += 0x8000u;
+  }
+  pk[1] = __builtin_amdgcn_perm(uro, ure, SEL);
+  if constexpr (NPL == 3) {
+    const float le = re - __uint_as_float(ure & 0xffff0000u), lo = ro - __uint_as_float(uro & 0xffff0000u);
+    pk[2] = __builtin_amdgcn_perm(__float_as_uint(lo), __float_as_uint(le), SEL);
+  }
+}
+
+// 8 consecutive-k fp32 values -> the three bf16x8 MFMA operand pieces
+__device__ __forceinline__ void split8(const f32x4& lo4, const f32x4& hi4, bf16x8 (&piece)[3]) {
+  unsigned q0[3], q1[3], q2[3], q3[3];
+  split_pair<3>(lo4[0], lo4[1], q0);
+  split_pair<3>(lo4[2], lo4[3], q1);
+  split_pair<3>(hi4[0], hi4[1], q2);
+  split_pair<3>(hi4[2], hi4[3], q3);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) piece[pl] = __builtin_bit_cast(bf16x8, (u32x4){q0[pl], q1[pl], q2[pl], q3[pl]});
+}
 
 }  // namespace rnnt

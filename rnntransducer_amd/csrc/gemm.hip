@@ -309,10 +309,6 @@ __global__ void __launch_bounds__(256, (NW == 4 ? 2 : 3)) gemm_f32_kernel(const 
 // row (k-contiguous operand) or 2-4 k of 4 neighbouring rows (row-contiguous operand) - store with at most 2-4-way
 // conflicts, which ds_write_b32/b64 absorb in their issue time.
 // ------------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
 template <int ROWS, int BKS>
 struct PlaneImg {
   static constexpr int RS = 2 * BKS + 16;           // bytes per row: payload + 16 pad (odd number of 16-B slots)
@@ -321,25 +317,6 @@ struct PlaneImg {
   static_assert(((ROWS / 4) * RS) % 256 == 0, "class distance must be 64 (mod 256)");
   static __device__ __forceinline__ int off(int r) { return (r & 3) * X + (r >> 2) * RS; }
 };
-
-// (even-k, odd-k) pair of fp32 -> one packed dword (2 x bf16) per piece
-template <int NPL>
-__device__ __forceinline__ void split_pair(float xe, float xo, unsigned (&pk)[NPL]) {
-  constexpr unsigned SEL = 0x07060302u;  // D = {S1.b2, S1.b3, S0.b2, S0.b3}: upper halves of (even, odd)
-  const unsigned ue = __float_as_uint(xe), uo = __float_as_uint(xo);
-  pk[0] = __builtin_amdgcn_perm(uo, ue, SEL);
-  const float re = xe - __uint_as_float(ue & 0xffff0000u), ro = xo - __uint_as_float(uo & 0xffff0000u);
-  unsigned ure = __float_as_uint(re), uro = __float_as_uint(ro);
-  if constexpr (NPL == 2) {  // last piece kept: round it to nearest instead of truncating
-    ure += 0x8000u;
-    uro += 0x8000u;
-  }
-  pk[1] = __builtin_amdgcn_perm(uro, ure, SEL);
-  if constexpr (NPL == 3) {
-    const float le = re - __uint_as_float(ure & 0xffff0000u), lo = ro - __uint_as_float(uro & 0xffff0000u);
-    pk[2] = __builtin_amdgcn_perm(__float_as_uint(lo), __float_as_uint(le), SEL);
-  }
-}
 
 // Global fp32 -> registers -> NPL bf16 piece images in LDS, for a (ROWS) x (BKS k) operand tile and 256 threads.
 // KC (k-contiguous rows): BKS/4 threads per row, each one float4 = 4 consecutive k; with BKS = 32 a row's 128 bytes are

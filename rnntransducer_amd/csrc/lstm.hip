@@ -734,6 +734,191 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
   }
 }
 
+// ================================================================================================
+// v3 forward: the recurrent product on the bf16 matrix cores, W_hh stationary in REGISTERS.
+//
+// Same decomposition as v2 (sync groups = direction x batch slice, a workgroup owns HS = 16 hidden units, split-K over the
+// 4 waves), but h_{t-1} . W_hh^T runs as v_mfma_f32_16x16x32_bf16 on exact bf16 pieces (common.hpp: 6 piece products =
+// fp32 accuracy) instead of v_mfma_f32_4x4x1_16B_f32: 96 MFMAs x 16 cycles per wave and step instead of 256 x 12.2.
+//   M = the workgroup's 64 gate columns (4 blocks of 16 = 4 units x 4 gate slots), N = the group's batch rows (<= 16),
+//   K = this wave's quarter of the hidden vector (NKS steps of 32).
+//   A (stationary): lane -> gate column 16*mb + (lane&15), k = 32*ks + 8*(lane>>4) + e: the wave's W_hh slice as
+//     3 bf16 pieces = 4*NKS*12 VGPRs, split once at kernel start: no LDS copy of the weights, no per-step weight reads.
+//   B (per step): lane -> batch row (lane&15), the same 8 consecutive k: exactly 32 contiguous bytes of the row-major
+//     exchange buffer, so the gather is two 16-B sc1 loads per k-step straight into registers (no LDS stage), then split.
+//   D: lane -> (unit 4*mb + (lane>>4), row lane&15), its 4 registers = the 4 gate slots of that cell.
+// Cross-wave reduction through LDS; wave w then owns units 4w..4w+3: one cell per lane, no DPP gymnastics.
+// Stash layouts (gates, cst, y) are those of v2, so lstm_bwd2_kernel consumes them unchanged.
+// dynamic LDS: part[4 waves][4 mb][64] f32x4 | abort
+// ================================================================================================
+template <int NKS, int CELL>
+__global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
+  constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
+  constexpr int HS = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  constexpr int Kw = 32 * NKS;
+  f32x4* part = reinterpret_cast<f32x4*>(smem);
+  int* abort_lds = reinterpret_cast<int*>(part + 16 * 64);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NG = D * p.G;
+  const int gid = blockIdx.x % NG, wg = blockIdx.x / NG;
+  const int d = gid / p.G, g = gid % p.G;
+  const int b0 = g * p.Bg, j0 = wg * HS;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  bf16x8 wp[4][NKS][3];
+  {
+    const float* W = p.w_hh[d];
+    const int gate = lrow & 3;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const float* row = W + (long)(gate * H + j0 + 4 * mb + (lrow >> 2)) * H;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int k = wave * Kw + 32 * ks + 8 * lq;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (gate < NGATE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (k + e < H) lo[e] = row[k + e];
+            if (k + 4 + e < H) hi[e] = row[k + 4 + e];
+          }
+        }
+        split8(lo, hi, wp[mb][ks]);
+      }
+    }
+    if (tid == 0) *abort_lds = 0;
+  }
+  const int NBR = 4 * ((p.Bg + 3) / 4);  // exchange rows of the group (as allocated by the host: 4*BQ)
+  const long hx_floats = (long)NBR * Kp;
+  __amdgpu_buffer_rsrc_t hx_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    hx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(p.hx + ((long)par * NG + gid) * hx_floats, 0, (int)(hx_floats * 4), RSRC_FLAGS);
+  unsigned* flags = p.flags + gid * p.NC;
+
+  // one cell per lane: unit 4*wave + lq of this workgroup, batch row lrow of this group
+  const int brow = lrow;
+  const int ob = b0 + brow, oj = j0 + 4 * wave + lq;
+  const bool inrow = brow < NBR;
+  const bool valid = brow < p.Bg && ob < B;
+  const int olen = valid ? p.lens[ob] : 0;
+  float c_state = 0.f;
+  const float bhn = (CELL == 1) ? p.b_hh[d][2 * H + oj] : 0.f;
+  const int t_first = (d == 0) ? 0 : T - 1;
+  const long tdir = (d == 0) ? 1 : -1;
+  long g_off = (((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj;
+  long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3);
+  long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
+  const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
+  const int hx_off = (brow * Kp + oj) * 4;
+  const int gat_off = inrow ? (brow * Kp + wave * Kw + 8 * lq) * 4 : 0x7ffffff0;  // rows beyond the group read 0
+  __syncthreads();
+  unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
+  const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
+
+  auto run = [&](auto local_tag) -> bool {
+  constexpr bool LOCAL = decltype(local_tag)::value;
+  for (int s = 0; s < T; ++s) {
+    const int t = (d == 0) ? s : T - 1 - s;
+    f32x4 xp = {0.f, 0.f, 0.f, 0.f};
+    if (valid) xp = *reinterpret_cast<const f32x4*>(p.gates + g_off);
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    DBG_STAMP(0);
+    if (s > 0) {
+      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return false;
+      DBG_STAMP(1);
+      i32x4 raw[NKS][2];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc[(s - 1) & 1], gat_off + 128 * ks, 0, AUX_SC1);
+        raw[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc[(s - 1) & 1], gat_off + 128 * ks + 16, 0, AUX_SC1);
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        bf16x8 hp[3];
+        split8(__builtin_bit_cast(f32x4, raw[ks][0]), __builtin_bit_cast(f32x4, raw[ks][1]), hp);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][2], hp[0], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], hp[1], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], hp[2], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], hp[0], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], hp[1], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], hp[0], acc[mb], 0, 0, 0);
+        }
+      }
+      DBG_STAMP(2);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) part[(wave * 4 + mb) * 64 + lane] = acc[mb];
+    __syncthreads();
+    f32x4 rec = part[wave * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) rec += part[(w * 4 + wave) * 64 + lane];
+    const bool active = valid && t < olen;
+    float hval = 0.f;
+    f32x4 gact = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      if constexpr (CELL == 0) {
+        const f32x4 g4 = xp + rec;
+        const float ig = sig_sel(g4[0], p.hw_math), fg = sig_sel(g4[1], p.hw_math), gg = tanh_sel(g4[2], p.hw_math), og = sig_sel(g4[3], p.hw_math);
+        c_state = fg * c_state + ig * gg;
+        hval = og * tanh_sel(c_state, p.hw_math);
+        gact = (f32x4){ig, fg, gg, og};
+      } else if constexpr (CELL == 1) {
+        const float rg = sig_sel(xp[0] + rec[0], p.hw_math), zg = sig_sel(xp[1] + rec[1], p.hw_math);
+        const float hn = rec[2] + bhn;
+        const float ng = tanh_sel(xp[2] + rg * hn, p.hw_math);
+        hval = (1.f - zg) * ng + zg * c_state;
+        c_state = hval;
+        gact = (f32x4){rg, zg, ng, hn};
+      } else {
+        const float pre = xp[0] + rec[0];
+        hval = (p.cell == RNNT_CELL_RNN_RELU) ? fmaxf(pre, 0.f) : tanh_sel(pre, p.hw_math);
+        c_state = hval;
+        gact = (f32x4){hval, 0.f, 0.f, 0.f};
+      }
+    } else {
+      c_state = 0.f;
+    }
+    if (inrow) {  // ONLY the exchange slice is stored before the flag
+      if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hval), hx_rsrc[s & 1], hx_off, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hval), hx_rsrc[s & 1], hx_off, 0, AUX_SC1);
+    }
+    DBG_STAMP(3);
+    publish_flag2<LOCAL>(flags + wg, (unsigned)(s + 1));
+    DBG_STAMP(4);
+    if (valid) {
+      *reinterpret_cast<f32x4*>(p.gates + g_off) = gact;
+      if constexpr (CELL == 0) p.cst[c_off] = c_state;
+      p.y[y_off] = hval;
+      if (p.ydrop)
+        p.ydrop[y_off] = (hash_u32(p.seed, (unsigned long long)y_off) >= p.drop_thresh) ? hval * p.keep_scale : 0.f;
+    }
+    g_off += g_step;
+    c_off += c_step;
+    y_off += y_step;
+    DBG_STAMP(5);
+  }
+  return true;
+  };
+  const bool ok = local ? run(std::true_type{}) : run(std::false_type{});
+  if (!ok) return;
+  if (p.dbg && tid == 0) {
+    for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    p.dbg[blockIdx.x * 8 + 6] = local ? 1 : 0;
+    p.dbg[blockIdx.x * 8 + 7] = xcc_id & 0xf;
+  }
+}
+
 // dynamic LDS: WA[4][Ls/4][64] f32x4 | hs[4][stage_floats] | part[4][BQ][64] f32x4 | abort
 template <int HS, int BQ, int CELL>
 __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
@@ -1322,7 +1507,23 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   Plan2 p2;
   if (make_plan2(d->B, d->H, d->D, device_cus(), &p2)) {
     k.NC = p2.NC; k.Hs = p2.HS; k.G = p2.G; k.Bg = p2.Bg; k.Kp = p2.Kp;
-    DISPATCH_HS_BQ(lstm_fwd2_kernel, d->cell, p2, k, p2, p2.lds_fwd, s, "lstm_fwd2");
+    const int nks = p2.Kp / 128;
+    if (p2.HS == 16 && p2.Kp % 128 == 0 && p2.Kp == d->H && (nks == 1 || nks == 2 || nks == 4 || nks == 5) && !getenv("RNNT_LSTM_V2")) {
+      const size_t lds3 = 16 * 64 * 16 + 16;
+#define LAUNCH_V3(N)                                                                                              \
+      do {                                                                                                        \
+        if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<N, 0>, k, p2, lds3, s, "lstm_fwd3"); \
+        else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1>, k, p2, lds3, s, "lstm_fwd3"); \
+        else rc = launch_persistent2(lstm_fwd3_kernel<N, 2>, k, p2, lds3, s, "lstm_fwd3");                         \
+      } while (0)
+      if (nks == 1) LAUNCH_V3(1);
+      else if (nks == 2) LAUNCH_V3(2);
+      else if (nks == 4) LAUNCH_V3(4);
+      else LAUNCH_V3(5);
+#undef LAUNCH_V3
+    } else {
+      DISPATCH_HS_BQ(lstm_fwd2_kernel, d->cell, p2, k, p2, p2.lds_fwd, s, "lstm_fwd2");
+    }
   } else if (d->cell == RNNT_CELL_LSTM) {
     DISPATCH_MT_NT(lstm_fwd_kernel, pl, k, pl, pl.lds_fwd, s, "lstm_fwd");
   } else {
