@@ -1079,6 +1079,224 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
   }
 }
 
+// ================================================================================================
+// v4 backward ("scatter form"): the recurrent product dh_{t-1} = dG_t . W_hh with the roles of the exchange swapped.
+//
+// v2 gathers ALL of dG_t (rows x 4H: 64 KB per workgroup and step at H = 512) and multiplies by its 16 columns of W_hh.
+// Here a workgroup multiplies ITS OWN 64 gate columns of dG_t (rows x 64, local, produced by its own cell math) by its 64
+// ROWS of W_hh and publishes the partial dh_{t-1} for ALL hidden units (rows x H); a consumer then sums, for its 16 units,
+// the NC partial slices (NC x rows x 16 floats = 16 KB at H = 512: the forward's exchange volume, a quarter of v2's).
+// The product runs on the bf16 matrix cores on exact bf16 pieces (common.hpp), W_hh stationary in registers:
+//   M = output units (this wave's Kp/64 blocks of 16), N = the group's batch rows (<= 16), K = the 64 own gate columns
+//   (2 steps of 32);  A: lane -> output unit 16*mb + (lane&15), k = 32*ks + 8*(lane>>4) + e = 4*(own unit) + gate;
+//   B: lane -> row (lane&15), the same 8 gate columns, read from a 4 KB LDS image of the cell math's dG and split;
+//   D: lane -> (units 16*mb + 4*(lane>>4) .. +3, row lane&15): one 16-byte store straight into the exchange buffer.
+// Exchange buffer: partial[parity][group][producer][row][Kp] fp32.  Protocol, owners, cell math and stash as in v2.
+// dynamic LDS: red[256] f32x4 | dgs[16][DGS_LD] float | abort
+// ================================================================================================
+template <int NKS, int BQ, int CELL>
+__global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
+  constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
+  constexpr int HS = 16, UQ = 4;
+  constexpr int NMB = 2 * NKS;          // 16-unit output blocks per wave: Kp/64 with Kp = 128*NKS
+  constexpr int NBR = 4 * BQ;           // exchange rows of the group
+  constexpr int DGS_LD = 68;            // floats per row of the dG image (64 + pad)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  float* dgs = reinterpret_cast<float*>(red + 256);
+  int* abort_lds = reinterpret_cast<int*>(dgs + 16 * DGS_LD);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NG = D * p.G;
+  const int gid = blockIdx.x % NG, wg = blockIdx.x / NG;
+  const int d = gid / p.G, g = gid % p.G;
+  const int b0 = g * p.Bg, j0 = wg * HS;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  bf16x8 wp[NMB][2][3];
+  {
+    const float* W = p.w_hh[d];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const int u = 16 * (wave * NMB + mb) + lrow;  // output unit = column of W_hh
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = 32 * ks + 8 * lq;             // own gate column 4*unit + gate; c is a multiple of 8
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (u < H) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (e < NGATE) {
+              lo[e] = W[(long)(e * H + j0 + (c >> 2)) * H + u];
+              hi[e] = W[(long)(e * H + j0 + (c >> 2) + 1) * H + u];
+            }
+          }
+        }
+        split8(lo, hi, wp[mb][ks]);
+      }
+    }
+    for (int i = tid; i < 16 * DGS_LD; i += 256) dgs[i] = 0.f;
+    if (tid == 0) *abort_lds = 0;
+  }
+  const long px_floats = (long)p.NC * NBR * Kp;  // one group's partials of one parity
+  __amdgpu_buffer_rsrc_t px_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    px_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(p.hx + ((long)par * NG + gid) * px_floats, 0, (int)(px_floats * 4), RSRC_FLAGS);
+  unsigned* flags = p.flags + gid * p.NC;
+
+  // cell owners (as v2): tid = ((obq*UQ + uq)*4 + i)*4 + j -> unit j0 + 4*uq + i, batch row 4*obq + j
+  const bool owner = tid < BQ * HS * 4;
+  const int ojb = tid & 3, oi = (tid >> 2) & 3, ouq = (tid >> 4) % UQ, obq = (tid >> 4) / UQ;
+  const int brow = 4 * obq + ojb, ob = b0 + brow, oj = j0 + 4 * ouq + oi;
+  const bool valid = owner && brow < p.Bg && ob < B;
+  const int olen = valid ? p.lens[ob] : 0;
+  float dc_carry = 0.f;
+  const int t_first = (d == 0) ? T - 1 : 0;
+  const long tdir = (d == 0) ? -1 : 1;
+  long g_off = (((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj;
+  long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3);
+  long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
+  const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
+  // gather: item idx = tid + 256*i -> (unit quad idx&3, row (idx>>2) % NBR, producer idx / (4*NBR)); 4*NBR divides 256, so a
+  // thread always meets the same (row, quad) and sums over the producers it visits
+  const int grow = (tid >> 2) % NBR, guq = tid & 3;
+  const int gat_base = ((tid / (4 * NBR)) * NBR + grow) * Kp + j0 + 4 * guq;  // floats; + 256/(4*NBR) producers per i
+  const int gat_step = (256 / (4 * NBR)) * NBR * Kp;
+  const int nitems = p.NC * NBR * 4;
+  // publish: lane -> row lrow, units 16*mbg + 4*lq .. +3
+  const int pub_base = lrow < NBR ? ((wg * NBR + lrow) * Kp + 16 * wave * NMB + 4 * lq) * 4 : 0x7ffffff0;
+  __syncthreads();
+  unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
+  const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
+
+  auto run = [&](auto local_tag) -> bool {
+  constexpr bool LOCAL = decltype(local_tag)::value;
+  for (int s = 0; s < T; ++s) {
+    const int t = (d == 0) ? T - 1 - s : s;
+    const int tprev = (d == 0) ? t - 1 : t + 1;
+    f32x4 gt = {0.f, 0.f, 0.f, 0.f};
+    float c_t = 0.f, c_p = 0.f, dyv = 0.f;
+    const bool active = valid && t < olen;
+    if (active) {
+      gt = *reinterpret_cast<const f32x4*>(p.gates + g_off);
+      if constexpr (CELL == 0) {
+        c_t = p.cst[c_off];
+        if (tprev >= 0 && tprev < T) c_p = p.cst[c_off + c_step];
+      } else if constexpr (CELL == 1) {
+        if (tprev >= 0 && tprev < T) c_p = p.y[y_off + y_step];
+      }
+      const long yo = y_off;
+      dyv = p.dy[yo];
+      if (p.ydrop) dyv = (hash_u32(p.seed, (unsigned long long)yo) >= p.drop_thresh) ? dyv * p.keep_scale : 0.f;
+    }
+    DBG_STAMP(0);  // prefetch issue
+    f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return false;
+      DBG_STAMP(1);  // flag wait
+      const __amdgpu_buffer_rsrc_t src = px_rsrc[(s - 1) & 1];
+      constexpr int NI = 4;
+      for (int i0 = 0; i0 * 256 < nitems; i0 += NI) {
+        i32x4 r[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const bool ok = (i0 + i) * 256 + tid < nitems;
+          r[i] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? (gat_base + (i0 + i) * gat_step) * 4 : 0x7ffffff0, 0, AUX_SC1);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) gsum += __builtin_bit_cast(f32x4, r[i]);
+      }
+    }
+    red[tid] = gsum;
+    __syncthreads();
+    DBG_STAMP(2);  // gather + partial sums
+    f32x4 dg4 = {0.f, 0.f, 0.f, 0.f}, dgh4 = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+      float dh = dyv;
+      constexpr int NQ = 256 / (4 * NBR);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dh += red[q * 4 * NBR + brow * 4 + ouq][oi];
+      if (active) {
+        if constexpr (CELL == 0) {
+          const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
+          const float tc = tanh_sel(c_t, p.hw_math);
+          const float dc = dh * og * (1.f - tc * tc) + dc_carry;
+          dg4[0] = dc * gg * ig * (1.f - ig);
+          dg4[1] = dc * c_p * fg * (1.f - fg);
+          dg4[2] = dc * ig * (1.f - gg * gg);
+          dg4[3] = dh * tc * og * (1.f - og);
+          dc_carry = dc * fg;
+          dgh4 = dg4;
+        } else if constexpr (CELL == 1) {
+          const float rg = gt[0], zg = gt[1], ng = gt[2], hn = gt[3];
+          dh += dc_carry;
+          const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+          const float dz_pre = dh * (c_p - ng) * zg * (1.f - zg);
+          const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+          dg4 = (f32x4){dr_pre, dz_pre, dn_pre, 0.f};
+          dgh4 = (f32x4){dr_pre, dz_pre, dn_pre * rg, 0.f};
+          dc_carry = dh * zg;
+        } else {
+          const float hv = gt[0];
+          const float dpre = (p.cell == RNNT_CELL_RNN_RELU) ? (hv > 0.f ? dh : 0.f) : dh * (1.f - hv * hv);
+          dg4 = (f32x4){dpre, 0.f, 0.f, 0.f};
+          dgh4 = dg4;
+        }
+      } else {
+        dc_carry = 0.f;
+      }
+      *reinterpret_cast<f32x4*>(&dgs[brow * DGS_LD + 4 * (4 * ouq + oi)]) = dgh4;  // own gate column 4*unit + gate
+    }
+    __syncthreads();
+    DBG_STAMP(3);  // LDS reduce + cell math
+    {
+      bf16x8 gp[2][3];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* src = dgs + lrow * DGS_LD + 32 * ks + 8 * lq;
+        split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), gp[ks]);
+      }
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][2], gp[ks][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], gp[ks][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], gp[ks][2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], gp[ks][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], gp[ks][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], gp[ks][0], acc, 0, 0, 0);
+        }
+        exchange_store<LOCAL>(__builtin_bit_cast(i32x4, acc), px_rsrc[s & 1], pub_base + 64 * mb);
+      }
+    }
+    publish_flag2<LOCAL>(flags + wg, (unsigned)(s + 1));
+    DBG_STAMP(4);  // MFMA + partial stores + drain + barrier + flag
+    if (valid) {
+      *reinterpret_cast<f32x4*>(p.gates + g_off) = dg4;
+      if constexpr (CELL == 1) *reinterpret_cast<f32x4*>(p.aux + g_off) = dgh4;
+    }
+    g_off += g_step;
+    c_off += c_step;
+    y_off += y_step;
+    DBG_STAMP(5);  // stash stores issue
+  }
+  return true;
+  };
+  const bool ok = local ? run(std::true_type{}) : run(std::false_type{});
+  if (!ok) return;
+  if (p.dbg && tid == 0) {
+    for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    p.dbg[blockIdx.x * 8 + 6] = local ? 1 : 0;
+    p.dbg[blockIdx.x * 8 + 7] = xcc_id & 0xf;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
@@ -1285,7 +1503,9 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
     if (cus <= 0) cus = 256;
     if (make_plan2(B, H, D, cus, &p2)) {
       const size_t nf2 = (size_t)D * p2.G * p2.NC;
-      const size_t hx2 = (size_t)2 * D * p2.G * 4 * p2.BQ * 4 * p2.Kp * 4;
+      size_t hx2 = (size_t)2 * D * p2.G * 4 * p2.BQ * 4 * p2.Kp * 4;
+      const size_t hx4 = (size_t)2 * D * p2.G * p2.NC * 4 * p2.BQ * p2.Kp * 4;  // v4 backward: per-producer partial dh
+      if (hx4 > hx2) hx2 = hx4;
       if (nf2 > nflags) nflags = nf2;
       if (hx2 > hxb) hxb = hx2;
     }
@@ -1560,7 +1780,31 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   Plan2 p2;
   if (make_plan2(d->B, d->H, d->D, device_cus(), &p2)) {
     k.NC = p2.NC; k.Hs = p2.HS; k.G = p2.G; k.Bg = p2.Bg; k.Kp = p2.Kp;
-    DISPATCH_HS_BQ(lstm_bwd2_kernel, d->cell, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
+    const int nks = p2.Kp / 128;
+    if (p2.HS == 16 && p2.Kp % 128 == 0 && p2.Kp == d->H && (nks == 1 || nks == 2 || nks == 4) && !getenv("RNNT_LSTM_V2")) {
+      const size_t lds4 = 256 * 16 + 16 * 68 * 4 + 16;
+#define LAUNCH_V4_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<N, BQ_, C>, k, p2, lds4, s, "lstm_bwd4")
+#define LAUNCH_V4_B(N, C)                           \
+      do {                                          \
+        if (p2.BQ == 1) LAUNCH_V4_C(N, 1, C);       \
+        else if (p2.BQ == 2) LAUNCH_V4_C(N, 2, C);  \
+        else LAUNCH_V4_C(N, 4, C);                  \
+      } while (0)
+#define LAUNCH_V4(N)                                               \
+      do {                                                         \
+        if (d->cell == RNNT_CELL_LSTM) LAUNCH_V4_B(N, 0);          \
+        else if (d->cell == RNNT_CELL_GRU) LAUNCH_V4_B(N, 1);      \
+        else LAUNCH_V4_B(N, 2);                                    \
+      } while (0)
+      if (nks == 1) LAUNCH_V4(1);
+      else if (nks == 2) LAUNCH_V4(2);
+      else LAUNCH_V4(4);
+#undef LAUNCH_V4
+#undef LAUNCH_V4_B
+#undef LAUNCH_V4_C
+    } else {
+      DISPATCH_HS_BQ(lstm_bwd2_kernel, d->cell, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
+    }
   } else if (d->cell == RNNT_CELL_LSTM) {
     DISPATCH_MT_NT(lstm_bwd_kernel, pl, k, pl, pl.lds_bwd, s, "lstm_bwd");
   } else {
