@@ -318,14 +318,14 @@ struct PlaneImg {
   static __device__ __forceinline__ int off(int r) { return (r & 3) * X + (r >> 2) * RS; }
 };
 
-// Global fp32 -> registers -> NPL bf16 piece images in LDS, for a (ROWS) x (BKS k) operand tile and 256 threads.
+// Global fp32 -> registers -> NPL bf16 piece images in LDS, for a (ROWS) x (BKS k) operand tile and NT threads.
 // KC (k-contiguous rows): BKS/4 threads per row, each one float4 = 4 consecutive k; with BKS = 32 a row's 128 bytes are
 // one whole cache line.  !KC (row-contiguous): a thread takes 4 neighbouring rows x NP CONSECUTIVE k.
-template <bool KC, bool VEC4, int ROWS, int BKS, int NPL>
+template <bool KC, bool VEC4, int ROWS, int BKS, int NPL, int NT = 256>
 struct SplitIO {
-  static constexpr int NP = ROWS * BKS / 1024;      // float4 per thread per K-tile
+  static constexpr int NP = ROWS * BKS / (4 * NT);  // float4 per thread per K-tile
   static constexpr int TPK = BKS / 4;               // KC: threads per row
-  static constexpr int RPP = 256 / TPK;             // KC: rows per pass
+  static constexpr int RPP = NT / TPK;              // KC: rows per pass
   static constexpr int TPR = ROWS / 4;              // !KC: threads per k-row
   static_assert(NP == 2 || NP == 4, "tile shape");
   using Img = PlaneImg<ROWS, BKS>;
@@ -556,6 +556,108 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16s_kernel(const GemmK p) {
   epilogue<NW>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// 256x256x16 tile, 512 threads (8 waves as 4 x 2, each 64 x 128), ONE workgroup per CU, bf16 piece images double-buffered
+// in 147 KB of LDS, one barrier per K-tile.  Why (tools/gemm_phase_probe.py on the 128x256 form): a CU's vector-memory path
+// needs 1.5-3.3 k cycles to take the six wave-loads of a K-tile from each of its 8 waves, and nothing overlapped that with
+// the 1.5 k cycles of MFMAs; this form moves a third fewer operand bytes per FLOP through that path (4 wave-loads per
+// 64x128x16 of output instead of 6) and staggers the two waves of every SIMD: waves 0-3 split + store the next tile and issue
+// their loads BEFORE their MFMAs, waves 4-7 AFTER, so one wave's VALU / LDS-store / load-issue phase runs under the other
+// wave's MFMAs.
+template <bool A_KC, bool B_KC, bool VEC4, int NPROD>
+__global__ void __launch_bounds__(512, 1) gemm_bf16s256_kernel(const GemmK p) {
+  constexpr int BMB = 256, BNB = 256, NW = 4, NT = 512;
+  constexpr int NPL = NPROD == 6 ? 3 : 2;
+  using IA = PlaneImg<BMB, BK>;
+  using IB = PlaneImg<BNB, BK>;
+  constexpr int STAGE = NPL * (IA::BYTES + IB::BYTES);
+  extern __shared__ __attribute__((aligned(16))) char lds256[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_m = (p.M + BMB - 1) / BMB, tiles_n = (p.N + BNB - 1) / BNB;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (bid % tiles_m) * BMB, n0 = (bid / tiles_m) * BNB;
+
+  SplitIO<A_KC, VEC4, BMB, BK, NPL, NT> ta;
+  SplitIO<B_KC, VEC4, BNB, BK, NPL, NT> tb;
+  setup_split_io<A_KC, B_KC>(ta, tb, p, m0, n0);
+
+  f32x16 acc[2][NW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  ta.K = tb.K = kend;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  int aoff[2], boff[NW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aoff[i] = IA::off(wm * 64 + i * 32 + (lane & 31)) + 16 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < NW; ++j) boff[j] = NPL * IA::BYTES + IB::off(wn * 128 + j * 32 + (lane & 31)) + 16 * (lane >> 5);
+
+  auto stage_store = [&](int buf) {
+    ta.store(lds256 + buf * STAGE);
+    tb.store(lds256 + buf * STAGE + NPL * IA::BYTES);
+  };
+  auto mma_tile = [&](int buf) {
+    const char* base = lds256 + buf * STAGE;
+    bf16x8 af[2][NPL], bf[NW][NPL];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + aoff[i] + pl * IA::BYTES));
+#pragma unroll
+      for (int j = 0; j < NW; ++j) bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + boff[j] + pl * IB::BYTES));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        if constexpr (NPROD == 6) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  ta.load(kbeg);
+  tb.load(kbeg);
+  stage_store(0);
+  ta.load(kbeg + BK);
+  tb.load(kbeg + BK);
+  __syncthreads();
+  const bool early = wave < 4;  // wave-uniform: which half of the workgroup feeds the next tile before its MFMAs
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (early) {
+      stage_store(cur ^ 1);                 // tile kt+1 (zeros past the end); buffer cur^1 was last read before the previous barrier
+      ta.load(kbeg + (kt + 2) * BK);
+      tb.load(kbeg + (kt + 2) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tile(cur);
+    } else {
+      mma_tile(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_store(cur ^ 1);
+      ta.load(kbeg + (kt + 2) * BK);
+      tb.load(kbeg + (kt + 2) * BK);
+    }
+    __syncthreads();
+  }
+  epilogue<NW>(p, acc, m0, n0, wm, wn, lane);
+}
+
 // how the GEMMs multiply: 6 = split-bf16 with all terms of fp32 weight (default), 3 = split-bf16 first-order only,
 // 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fma chains).  RNNT_GEMM_MODE = bf16x6 | bf16x3 | f32.
 inline int gemm_mode() {
@@ -595,15 +697,19 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 extern "C" size_t rnnt_hip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   // enough for the split count rnnt_hip_gemm_f32 would pick; 0 when it would not split
   if (M <= 0 || N <= 0 || K < 8 * rnnt::BK) return 0;
-  const int mode = rnnt::gemm_mode();
-  const int bn = (mode && getenv("RNNT_GEMM_BK32")) ? 128 : rnnt::pick_bn(M, N);
-  const long tiles = rnnt::ceil_div(M, rnnt::BM) * rnnt::ceil_div(N, bn);
-  if (tiles >= 512) return 0;
-  long want = rnnt::ceil_div(1024, tiles);
+  // the larger of what the 128-row tilings (2 workgroups per CU) and the 256x256 tiling (1 per CU) would ask for
   const long by_k = K / (8 * rnnt::BK);
-  if (want > by_k) want = by_k;
-  if (want > 64) want = 64;
-  return want >= 2 ? (size_t)want * M * N * 4 : 0;
+  long best = 0;
+  for (int big = 0; big < 2; ++big) {
+    const long tiles = big ? rnnt::ceil_div(M, 256) * rnnt::ceil_div(N, 256)
+                           : rnnt::ceil_div(M, rnnt::BM) * rnnt::ceil_div(N, 128);
+    if (tiles >= (big ? 256 : 512)) continue;
+    long want = rnnt::ceil_div(big ? 512 : 1024, tiles);
+    if (want > by_k) want = by_k;
+    if (want > 64) want = 64;
+    if (want > best) best = want;
+  }
+  return best >= 2 ? (size_t)best * M * N * 4 : 0;
 }
 
 extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
@@ -642,12 +748,15 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   const int mode = (d->flags & RNNT_GEMM_EXACT_F32) ? 0 : gemm_mode();
   const int bks = (mode && getenv("RNNT_GEMM_BK32")) ? 32 : BK;  // K-tile depth 32 (128x128 tiles only): measured slower
   const int bn = (mode && bks == 32) ? 128 : pick_bn(d->M, d->N);
-  const int tiles = (int)(ceil_div(d->M, BM) * ceil_div(d->N, bn));
+  // 256x256 tiles / 512 threads / one workgroup per CU for the split-bf16 form when the output is large in both directions
+  const bool big = mode != 0 && bks == BK && d->M >= 256 && d->N >= 256 && !getenv("RNNT_GEMM_NO256");
+  const int tiles = big ? (int)(ceil_div(d->M, 256) * ceil_div(d->N, 256)) : (int)(ceil_div(d->M, BM) * ceil_div(d->N, bn));
+  const int slots = big ? 256 : 512;  // workgroups the chip holds at once
   // split-K when the output has too few tiles to fill 256 CUs and K is deep (weight-gradient GEMMs):
   // partial slabs in the caller's workspace, summed in fixed order (bitwise reproducible; no float atomics)
   int splits = 1;
-  if (d->workspace && tiles < 512 && d->K >= 8 * BK) {
-    long want = ceil_div(1024, tiles);
+  if (d->workspace && tiles < slots && d->K >= 8 * BK) {
+    long want = ceil_div(2 * slots, tiles);
     const long by_k = d->K / (8 * BK);
     const long by_ws = (long)(d->workspace_bytes / ((size_t)d->M * d->N * 4));
     if (want > by_k) want = by_k;
@@ -661,7 +770,20 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   k.slab = (float*)d->workspace;
   dim3 grid(tiles, splits), block(256);
   hipStream_t s = (hipStream_t)stream;
+  constexpr int LDS256_6 = 2 * 3 * (PlaneImg<256, BK>::BYTES * 2), LDS256_3 = 2 * 2 * (PlaneImg<256, BK>::BYTES * 2);
   ProfScope prof(RNNT_K_GEMM, 2.0 * (double)d->M * (double)d->N * (double)d->K, s);
+#define LAUNCH_BIG(AK, BKC, V)                                                                                          \
+  do {                                                                                                                  \
+    if (mode == 6) {                                                                                                    \
+      RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16s256_kernel<AK, BKC, V, 6>,                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_6));                        \
+      hipLaunchKernelGGL((gemm_bf16s256_kernel<AK, BKC, V, 6>), grid, dim3(512), LDS256_6, s, k);                       \
+    } else {                                                                                                            \
+      RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16s256_kernel<AK, BKC, V, 3>,                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_3));                        \
+      hipLaunchKernelGGL((gemm_bf16s256_kernel<AK, BKC, V, 3>), grid, dim3(512), LDS256_3, s, k);                       \
+    }                                                                                                                   \
+  } while (0)
 #define LAUNCH_K(KERNEL4, KERNEL2)                                        \
   do {                                                                    \
     if (bn == 256) hipLaunchKernelGGL((KERNEL4), grid, block, 0, s, k);   \
@@ -669,7 +791,8 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   } while (0)
 #define LAUNCH(AK, BKC, V)                                                                                              \
   do {                                                                                                                  \
-    if (mode == 6 && bks == 16 && bn == 256 && splits == 1 && d->workspace && getenv("RNNT_GEMM_DBG"))                  \
+    if (big) LAUNCH_BIG(AK, BKC, V);                                                                                    \
+    else if (mode == 6 && bks == 16 && bn == 256 && splits == 1 && d->workspace && getenv("RNNT_GEMM_DBG"))             \
       hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 4, 6, 16, true>), grid, block, 0, s, k);                        \
     else if (mode == 6 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 6, 32>), grid, block, 0, s, k);    \
     else if (mode == 3 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 3, 32>), grid, block, 0, s, k); \
@@ -683,6 +806,7 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   else { if (vec) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
 #undef LAUNCH_K
 #undef LAUNCH
+#undef LAUNCH_BIG
   RNNT_CHECK_LAUNCH();
   if (splits > 1) {
     const long blocks = ceil_div((long)d->M * d->N, 256);
