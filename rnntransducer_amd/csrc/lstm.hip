@@ -744,8 +744,10 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
 //   K = this wave's quarter of the hidden vector (NKS steps of 32).
 //   A (stationary): lane -> gate column 16*mb + (lane&15), k = 32*ks + 8*(lane>>4) + e: the wave's W_hh slice as
 //     3 bf16 pieces = 4*NKS*12 VGPRs, split once at kernel start: no LDS copy of the weights, no per-step weight reads.
-//   B (per step): lane -> batch row (lane&15), the same 8 consecutive k: exactly 32 contiguous bytes of the row-major
-//     exchange buffer, so the gather is two 16-B sc1 loads per k-step straight into registers (no LDS stage), then split.
+//   B (per step): lane -> batch row (lane&15), the same 8 consecutive k.  The PRODUCER of a hidden value splits it (one cell
+//     per lane: 4 VALU) and publishes three bf16 planes [row][Kp]; a consumer's operand piece is then 16 contiguous bytes:
+//     three 16-B sc1 loads per k-step straight into MFMA operand registers, no LDS stage and no split on the critical path
+//     (splitting at the consumers cost 176 VALU per lane and step in every one of the group's 32 workgroups).
 //   D: lane -> (unit 4*mb + (lane>>4), row lane&15), its 4 registers = the 4 gate slots of that cell.
 // Cross-wave reduction through LDS; wave w then owns units 4w..4w+3: one cell per lane, no DPP gymnastics.
 // Stash layouts (gates, cst, y) are those of v2, so lstm_bwd2_kernel consumes them unchanged.
@@ -792,11 +794,14 @@ __global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
     if (tid == 0) *abort_lds = 0;
   }
   const int NBR = 4 * ((p.Bg + 3) / 4);  // exchange rows of the group (as allocated by the host: 4*BQ)
-  const long hx_floats = (long)NBR * Kp;
+  // the exchange carries h already split by its producer: three bf16 planes [row][Kp] per (parity, group), 6 bytes per value
+  const int plane_b = NBR * Kp * 2;
+  const long hx_bytes = 3l * plane_b;
   __amdgpu_buffer_rsrc_t hx_rsrc[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par)
-    hx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(p.hx + ((long)par * NG + gid) * hx_floats, 0, (int)(hx_floats * 4), RSRC_FLAGS);
+    hx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.hx) + ((long)par * NG + gid) * hx_bytes, 0,
+                                                     (int)hx_bytes, RSRC_FLAGS);
   unsigned* flags = p.flags + gid * p.NC;
 
   // one cell per lane: unit 4*wave + lq of this workgroup, batch row lrow of this group
@@ -813,8 +818,8 @@ __global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
   long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3);
   long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
   const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
-  const int hx_off = (brow * Kp + oj) * 4;
-  const int gat_off = inrow ? (brow * Kp + wave * Kw + 8 * lq) * 4 : 0x7ffffff0;  // rows beyond the group read 0
+  const int hx_off = (brow * Kp + oj) * 2;
+  const int gat_off = inrow ? (brow * Kp + wave * Kw + 8 * lq) * 2 : 0x7ffffff0;  // rows beyond the group read 0
   __syncthreads();
   unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
   const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
@@ -833,16 +838,17 @@ __global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
     if (s > 0) {
       if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return false;
       DBG_STAMP(1);
-      i32x4 raw[NKS][2];
+      i32x4 raw[NKS][3];
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        raw[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc[(s - 1) & 1], gat_off + 128 * ks, 0, AUX_SC1);
-        raw[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc[(s - 1) & 1], gat_off + 128 * ks + 16, 0, AUX_SC1);
-      }
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          raw[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc[(s - 1) & 1], gat_off + 64 * ks + pl * plane_b, 0, AUX_SC1);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         bf16x8 hp[3];
-        split8(__builtin_bit_cast(f32x4, raw[ks][0]), __builtin_bit_cast(f32x4, raw[ks][1]), hp);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) hp[pl] = __builtin_bit_cast(bf16x8, raw[ks][pl]);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
           acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][2], hp[0], acc[mb], 0, 0, 0);
@@ -887,9 +893,15 @@ __global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
     } else {
       c_state = 0.f;
     }
-    if (inrow) {  // ONLY the exchange slice is stored before the flag
-      if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hval), hx_rsrc[s & 1], hx_off, 0, 0);
-      else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hval), hx_rsrc[s & 1], hx_off, 0, AUX_SC1);
+    if (inrow) {  // ONLY the exchange slice is stored before the flag: h = h0 + h1 + h2 exactly, one bf16 per plane
+      const unsigned u0 = __float_as_uint(hval);
+      const float r1 = hval - __uint_as_float(u0 & 0xffff0000u);
+      const unsigned u1 = __float_as_uint(r1);
+      const unsigned u2 = __float_as_uint(r1 - __uint_as_float(u1 & 0xffff0000u));
+      constexpr int AUX = LOCAL ? 0 : AUX_SC1;
+      __builtin_amdgcn_raw_buffer_store_b16((short)(u0 >> 16), hx_rsrc[s & 1], hx_off, 0, AUX);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(u1 >> 16), hx_rsrc[s & 1], hx_off + plane_b, 0, AUX);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(u2 >> 16), hx_rsrc[s & 1], hx_off + 2 * plane_b, 0, AUX);
     }
     DBG_STAMP(3);
     publish_flag2<LOCAL>(flags + wg, (unsigned)(s + 1));
