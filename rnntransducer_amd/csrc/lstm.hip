@@ -62,6 +62,7 @@ struct LstmK {
   float* aux;      // GRU backward: hidden-side gate gradients (T,B,D,4H) for dW_hh / db_hh
   unsigned* xcc;   // v2: [D*G][NC] XCC id + 1 of every member, published once at kernel start (zeroed per launch)
   int allow_local; // v2: permit the L2-local exchange when a group is verified to sit on one XCD
+  int NGL;         // v2+: launch stride of the group index (>= D*G): gid = blockIdx % NGL, blocks with gid >= D*G exit at once
   int hw_math;     // v2: v_exp_f32 / v_rcp_f32 cell math (default; measured whole-model loss delta identical to the ocml expf +
                    // IEEE-division form, which RNNT_LSTM_EXACT_MATH=1 selects)
 };
@@ -585,7 +586,9 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = D * p.G;
-  const int gid = blockIdx.x % NG, wg = blockIdx.x / NG;  // consecutive ids -> different groups (XCD round-robin keeps a group on one XCD when NG == 8; speed only)
+  // consecutive ids -> different groups; with a launch stride of 8 the XCD round-robin keeps every group on one XCD (speed only)
+  const int gid = blockIdx.x % p.NGL, wg = blockIdx.x / p.NGL;
+  if (gid >= NG) return;
   const int d = gid / p.G, g = gid % p.G;
   const int b0 = g * p.Bg, j0 = wg * HS;
 
@@ -765,7 +768,8 @@ __global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = D * p.G;
-  const int gid = blockIdx.x % NG, wg = blockIdx.x / NG;
+  const int gid = blockIdx.x % p.NGL, wg = blockIdx.x / p.NGL;
+  if (gid >= NG) return;
   const int d = gid / p.G, g = gid % p.G;
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
@@ -946,7 +950,8 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = D * p.G;
-  const int gid = blockIdx.x % NG, wg = blockIdx.x / NG;
+  const int gid = blockIdx.x % p.NGL, wg = blockIdx.x / p.NGL;
+  if (gid >= NG) return;
   const int d = gid / p.G, g = gid % p.G;
   const int b0 = g * p.Bg, j0 = wg * HS;
 
@@ -1121,7 +1126,8 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = D * p.G;
-  const int gid = blockIdx.x % NG, wg = blockIdx.x / NG;
+  const int gid = blockIdx.x % p.NGL, wg = blockIdx.x / p.NGL;
+  if (gid >= NG) return;
   const int d = gid / p.G, g = gid % p.G;
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
@@ -1502,6 +1508,32 @@ bool make_plan2(int B, int H, int D, int cus, Plan2* pl) {
   return false;
 }
 
+// v3 / v4 (W_hh in registers, bf16 pieces): 16 units per workgroup, H a multiple of 128 with H/128 among the instantiated
+// k-step counts (H <= 640), no LDS constraint.
+bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
+  if (getenv("RNNT_LSTM_V1") || getenv("RNNT_LSTM_V2")) return false;
+  if (H % 128 != 0 || B < 1 || D < 1 || D > 2) return false;
+  const int nks = H / 128;
+  (void)bwd;
+  if (!(nks == 1 || nks == 2 || nks == 4 || nks == 5)) return false;  // H = 1024 (8 k-steps) lives off AGPR copies / spills: measured slower than v2
+  const int NC = H / 16;
+  const int Gmax = cus / (D * NC);
+  if (Gmax < 1) return false;
+  int G = (int)ceil_div(B, 4);
+  if (G > Gmax) G = Gmax;
+  const int Bg = (int)ceil_div(B, G);
+  if (Bg > 16) return false;
+  G = (int)ceil_div(B, Bg);
+  pl->HS = 16; pl->NC = NC; pl->G = G; pl->Bg = Bg; pl->BQ = Bg <= 4 ? 1 : (Bg <= 8 ? 2 : 4); pl->Kp = H;
+  pl->lds_fwd = 16 * 64 * 16 + 16;
+  pl->lds_bwd = 256 * 16 + 16 * 68 * 4 + 16;
+  return true;
+}
+
+// launch stride of the group index: 8 (= XCDs) when the groups fit one XCD each, so that the round-robin block -> XCD
+// placement puts all members of a group on one XCD (L2-local exchange); blocks of the unused group slots exit at once
+inline int group_launch_stride(int NG, int NC, int cus) { return (NG <= 8 && NC * 8 <= cus) ? 8 : NG; }
+
 LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
   LstmWs w;
   char* p = reinterpret_cast<char*>(ws);
@@ -1515,11 +1547,17 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
     if (cus <= 0) cus = 256;
     if (make_plan2(B, H, D, cus, &p2)) {
       const size_t nf2 = (size_t)D * p2.G * p2.NC;
-      size_t hx2 = (size_t)2 * D * p2.G * 4 * p2.BQ * 4 * p2.Kp * 4;
-      const size_t hx4 = (size_t)2 * D * p2.G * p2.NC * 4 * p2.BQ * p2.Kp * 4;  // v4 backward: per-producer partial dh
-      if (hx4 > hx2) hx2 = hx4;
+      const size_t hx2 = (size_t)2 * D * p2.G * 4 * p2.BQ * 4 * p2.Kp * 4;
       if (nf2 > nflags) nflags = nf2;
       if (hx2 > hxb) hxb = hx2;
+    }
+    for (int bwd = 0; bwd < 2; ++bwd) {
+      if (!make_plan3(B, H, D, cus, bwd != 0, &p2)) continue;
+      const size_t nf3 = (size_t)D * p2.G * p2.NC;
+      const size_t hx3 = bwd ? (size_t)2 * D * p2.G * p2.NC * 4 * p2.BQ * p2.Kp * 4   // v4: per-producer partial dh, fp32
+                             : (size_t)2 * D * p2.G * 4 * p2.BQ * p2.Kp * 6;          // v3: three bf16 planes of h
+      if (nf3 > nflags) nflags = nf3;
+      if (hx3 > hxb) hxb = hx3;
     }
   }
   w.nflags = nflags;
@@ -1574,9 +1612,10 @@ int launch_persistent2(K kernel, const LstmK& k, const Plan2& pl, size_t lds, hi
   int per_cu = 0;
   RNNT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
   const int cus = device_cus();
-  const int grid = k.D * pl.G * pl.NC;
-  if (per_cu < 1 || grid > cus) {
-    set_error("%s: %d workgroups cannot be co-resident (%d CUs x %d per CU)", what, grid, cus, per_cu);
+  const int active = k.D * pl.G * pl.NC;   // workgroups that take part (must be co-resident)
+  const int grid = k.NGL * pl.NC;          // launched: the idle group slots of an XCD-aligned launch exit immediately
+  if (per_cu < 1 || active > cus) {
+    set_error("%s: %d workgroups cannot be co-resident (%d CUs x %d per CU)", what, active, cus, per_cu);
     return RNNT_ERR_UNSUPPORTED;
   }
   {
@@ -1651,7 +1690,7 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->cell = d->cell;
   k->b_hh[0] = d->b_hh[0]; k->b_hh[1] = d->D > 1 ? d->b_hh[1] : d->b_hh[0];
   k->aux = d->aux;
-  k->G = 1; k->Bg = d->B; k->Kp = d->H;
+  k->G = 1; k->Bg = d->B; k->Kp = d->H; k->NGL = d->D;
   k->dbg = getenv("RNNT_LSTM_DBG") ? w.dbg : nullptr;
   k->xcc = w.flags + 16 + w.nflags;
   k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
@@ -1672,7 +1711,8 @@ extern "C" int32_t rnnt_hip_lstm_max_batch(int32_t H, int32_t D, int32_t cell) {
   for (int B = 64; B >= 1; --B) {
     Plan2 p2;
     Plan p1;
-    if (make_plan2(B, H, D, cus, &p2) || (cell == RNNT_CELL_LSTM && make_plan(B, H, D, cus, &p1))) { best = B; break; }
+    // the backward decides: a batch both directions of the recurrence can take
+    if (make_plan3(B, H, D, cus, true, &p2) || make_plan2(B, H, D, cus, &p2) || (cell == RNNT_CELL_LSTM && make_plan(B, H, D, cus, &p1))) { best = B; break; }
   }
   return best;
 }
@@ -1737,25 +1777,28 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   fill_kernel_args(d, pl, w, &k);
   int rc = RNNT_OK;
   Plan2 p2;
-  if (make_plan2(d->B, d->H, d->D, device_cus(), &p2)) {
-    k.NC = p2.NC; k.Hs = p2.HS; k.G = p2.G; k.Bg = p2.Bg; k.Kp = p2.Kp;
+  const int cus = device_cus();
+  auto adopt = [&](const Plan2& q) {
+    k.NC = q.NC; k.Hs = q.HS; k.G = q.G; k.Bg = q.Bg; k.Kp = q.Kp;
+    k.NGL = group_launch_stride(d->D * q.G, q.NC, cus);
+  };
+  if (make_plan3(d->B, d->H, d->D, cus, false, &p2)) {
+    adopt(p2);
     const int nks = p2.Kp / 128;
-    if (p2.HS == 16 && p2.Kp % 128 == 0 && p2.Kp == d->H && (nks == 1 || nks == 2 || nks == 4 || nks == 5) && !getenv("RNNT_LSTM_V2")) {
-      const size_t lds3 = 16 * 64 * 16 + 16;
 #define LAUNCH_V3(N)                                                                                              \
-      do {                                                                                                        \
-        if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<N, 0>, k, p2, lds3, s, "lstm_fwd3"); \
-        else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1>, k, p2, lds3, s, "lstm_fwd3"); \
-        else rc = launch_persistent2(lstm_fwd3_kernel<N, 2>, k, p2, lds3, s, "lstm_fwd3");                         \
-      } while (0)
-      if (nks == 1) LAUNCH_V3(1);
-      else if (nks == 2) LAUNCH_V3(2);
-      else if (nks == 4) LAUNCH_V3(4);
-      else LAUNCH_V3(5);
+    do {                                                                                                          \
+      if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<N, 0>, k, p2, p2.lds_fwd, s, "lstm_fwd3"); \
+      else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1>, k, p2, p2.lds_fwd, s, "lstm_fwd3"); \
+      else rc = launch_persistent2(lstm_fwd3_kernel<N, 2>, k, p2, p2.lds_fwd, s, "lstm_fwd3");                     \
+    } while (0)
+    if (nks == 1) LAUNCH_V3(1);
+    else if (nks == 2) LAUNCH_V3(2);
+    else if (nks == 4) LAUNCH_V3(4);
+    else LAUNCH_V3(5);
 #undef LAUNCH_V3
-    } else {
-      DISPATCH_HS_BQ(lstm_fwd2_kernel, d->cell, p2, k, p2, p2.lds_fwd, s, "lstm_fwd2");
-    }
+  } else if (make_plan2(d->B, d->H, d->D, cus, &p2)) {
+    adopt(p2);
+    DISPATCH_HS_BQ(lstm_fwd2_kernel, d->cell, p2, k, p2, p2.lds_fwd, s, "lstm_fwd2");
   } else if (d->cell == RNNT_CELL_LSTM) {
     DISPATCH_MT_NT(lstm_fwd_kernel, pl, k, pl, pl.lds_fwd, s, "lstm_fwd");
   } else {
@@ -1790,33 +1833,37 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   k.dy = bd->dy;
   int rc = RNNT_OK;
   Plan2 p2;
-  if (make_plan2(d->B, d->H, d->D, device_cus(), &p2)) {
-    k.NC = p2.NC; k.Hs = p2.HS; k.G = p2.G; k.Bg = p2.Bg; k.Kp = p2.Kp;
+  const int cus = device_cus();
+  auto adopt = [&](const Plan2& q) {
+    k.NC = q.NC; k.Hs = q.HS; k.G = q.G; k.Bg = q.Bg; k.Kp = q.Kp;
+    k.NGL = group_launch_stride(d->D * q.G, q.NC, cus);
+  };
+  if (make_plan3(d->B, d->H, d->D, cus, true, &p2)) {
+    adopt(p2);
     const int nks = p2.Kp / 128;
-    if (p2.HS == 16 && p2.Kp % 128 == 0 && p2.Kp == d->H && (nks == 1 || nks == 2 || nks == 4) && !getenv("RNNT_LSTM_V2")) {
-      const size_t lds4 = 256 * 16 + 16 * 68 * 4 + 16;
-#define LAUNCH_V4_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<N, BQ_, C>, k, p2, lds4, s, "lstm_bwd4")
+#define LAUNCH_V4_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<N, BQ_, C>, k, p2, p2.lds_bwd, s, "lstm_bwd4")
 #define LAUNCH_V4_B(N, C)                           \
-      do {                                          \
-        if (p2.BQ == 1) LAUNCH_V4_C(N, 1, C);       \
-        else if (p2.BQ == 2) LAUNCH_V4_C(N, 2, C);  \
-        else LAUNCH_V4_C(N, 4, C);                  \
-      } while (0)
+    do {                                            \
+      if (p2.BQ == 1) LAUNCH_V4_C(N, 1, C);         \
+      else if (p2.BQ == 2) LAUNCH_V4_C(N, 2, C);    \
+      else LAUNCH_V4_C(N, 4, C);                    \
+    } while (0)
 #define LAUNCH_V4(N)                                               \
-      do {                                                         \
-        if (d->cell == RNNT_CELL_LSTM) LAUNCH_V4_B(N, 0);          \
-        else if (d->cell == RNNT_CELL_GRU) LAUNCH_V4_B(N, 1);      \
-        else LAUNCH_V4_B(N, 2);                                    \
-      } while (0)
-      if (nks == 1) LAUNCH_V4(1);
-      else if (nks == 2) LAUNCH_V4(2);
-      else LAUNCH_V4(4);
+    do {                                                           \
+      if (d->cell == RNNT_CELL_LSTM) LAUNCH_V4_B(N, 0);            \
+      else if (d->cell == RNNT_CELL_GRU) LAUNCH_V4_B(N, 1);        \
+      else LAUNCH_V4_B(N, 2);                                      \
+    } while (0)
+    if (nks == 1) LAUNCH_V4(1);
+    else if (nks == 2) LAUNCH_V4(2);
+    else if (nks == 4) LAUNCH_V4(4);
+    else LAUNCH_V4(5);
 #undef LAUNCH_V4
 #undef LAUNCH_V4_B
 #undef LAUNCH_V4_C
-    } else {
-      DISPATCH_HS_BQ(lstm_bwd2_kernel, d->cell, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
-    }
+  } else if (make_plan2(d->B, d->H, d->D, cus, &p2)) {
+    adopt(p2);
+    DISPATCH_HS_BQ(lstm_bwd2_kernel, d->cell, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
   } else if (d->cell == RNNT_CELL_LSTM) {
     DISPATCH_MT_NT(lstm_bwd_kernel, pl, k, pl, pl.lds_bwd, s, "lstm_bwd");
   } else {
