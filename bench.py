@@ -174,7 +174,7 @@ def main():
     # the bf16 dense peak divided by the products one fp32 product costs.
     gemm_mode = os.environ.get("RNNT_GEMM_MODE") or "bf16x6"
     nprod = {"bf16x6": 6, "bf16x3": 3}.get(gemm_mode, 1)
-    gemm_name = "gemm_f32_kernel" if nprod == 1 else "gemm_bf16s_kernel"
+    gemm_name = "gemm_f32_kernel" if nprod == 1 else "gemm_bf16s_kernel"  # incl. its 256x256-tile form gemm_bf16s256_kernel
     gemm_peak = PEAK_FP32_MFMA_TFLOPS if nprod == 1 else PEAK_BF16_MFMA_TFLOPS / nprod
     if nprod > 1 and "gemm_f32_kernel" in kernels:  # the profiler's kind 0 is "the GEMM kernel", whichever form ran
         kernels = {(gemm_name if k == "gemm_f32_kernel" else k): v for k, v in kernels.items()}

@@ -8,7 +8,7 @@ import json
 import sqlite3
 import sys
 
-KINDS = (("gemm_bf16s_kernel", ("gemm_bf16s_kernel",)), ("gemm_f32_kernel", ("gemm_f32_kernel",)),
+KINDS = (("gemm_bf16s_kernel", ("gemm_bf16s_kernel", "gemm_bf16s256_kernel")), ("gemm_f32_kernel", ("gemm_f32_kernel",)),
          ("lstm_fwd_kernel", ("lstm_fwd3_kernel", "lstm_fwd2_kernel", "lstm_fwd_kernel")),
          ("lstm_bwd_kernel", ("lstm_bwd4_kernel", "lstm_bwd2_kernel", "lstm_bwd_kernel")),
          ("lse_kernel", ("lse_sep_kernel", "lse_dense_kernel")), ("alphabeta_kernel", ("alphabeta_kernel",)),
