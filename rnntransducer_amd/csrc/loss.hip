@@ -333,22 +333,56 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
       dCs[i] = 0.f;
     }
     __syncthreads();
-    for (int tl = wave; tl < TT; tl += 4) {
-      const int t = t0 + tl;
-      if (t >= T) break;
-      float acc = 0.f;
-      if (t < Tb && vok) {
-        const float a = Ab[(long)t * a_st + v];
-        for (int u = 0; u <= Ub; ++u) {
-          const CellS c = cells[tl * U1 + u];
-          float g = c.w * expf(a + Cs[u * 64 + lane] - c.lse);
+    // A wave owns the frames tl = wave + 4*i (i < TT/4) of the tile and walks u in chunks of UC: dA of a frame (sum over
+    // u) and dC of a label position (sum over the wave's frames) both accumulate in REGISTERS; the LDS adds that merge the
+    // four waves' dC happen once per (u, wave) instead of once per (u, frame) -- 8x fewer, and they were the kernel's
+    // bottleneck at large V (c5: V = 2048).
+    constexpr int NF = TT / 4, UC = 8;
+    float a[NF], accA[NF];
+    bool fok[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int t = t0 + wave + 4 * i;
+      fok[i] = t < Tb && vok;
+      a[i] = fok[i] ? Ab[(long)t * a_st + v] : 0.f;
+      accA[i] = 0.f;
+    }
+    for (int u0 = 0; u0 <= Ub; u0 += UC) {
+      float accC[UC], cs[UC];
+      int yv[UC];
+#pragma unroll
+      for (int j = 0; j < UC; ++j) {
+        const int u = min(u0 + j, U1 - 1);
+        accC[j] = 0.f;
+        cs[j] = Cs[u * 64 + lane];
+        yv[j] = ys[u];
+      }
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        if (!fok[i]) continue;
+        const CellS* crow = cells + (wave + 4 * i) * U1;
+#pragma unroll
+        for (int j = 0; j < UC; ++j) {
+          const int u = u0 + j;
+          if (u > Ub) break;
+          const CellS c = crow[u];
+          float g = c.w * expf(a[i] + cs[j] - c.lse);
           if (v == blank) g -= c.cb;
-          if (v == ys[u]) g -= c.ce;
-          acc += g;
-          atomicAdd(&dCs[u * 64 + lane], g);
+          if (v == yv[j]) g -= c.ce;
+          accA[i] += g;
+          accC[j] += g;
         }
       }
-      if (vok) dA[(long)b * a_sb + (long)t * a_st + v] = acc * gscale;
+      if (vok) {
+#pragma unroll
+        for (int j = 0; j < UC; ++j)
+          if (u0 + j <= Ub) atomicAdd(&dCs[(u0 + j) * 64 + lane], accC[j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int t = t0 + wave + 4 * i;
+      if (t < T && vok) dA[(long)b * a_sb + (long)t * a_st + v] = accA[i] * gscale;
     }
     __syncthreads();
     for (int i = tid; i < U1 * 64; i += 256) {
