@@ -23,7 +23,11 @@ def _oracle(x, lens, ref, dy):
 @pytest.mark.parametrize("B,T,I,H,L,bi", [(1, 1, 4, 4, 1, False), (3, 7, 5, 8, 1, True), (2, 9, 12, 12, 2, True),
                                           (5, 20, 80, 16, 2, True), (17, 13, 8, 32, 1, False), (33, 6, 16, 20, 1, True),
                                           (4, 30, 80, 128, 1, True), (64, 5, 8, 8, 1, True), (2, 25, 16, 512, 1, True),
-                                          (3, 12, 40, 640, 1, True)])
+                                          (3, 12, 40, 640, 1, True),
+                                          # register-resident bf16-piece kernels (H % 128 == 0): 16-row groups, H = 256 two layers
+                                          # one direction, prediction-net shape (one direction, 4-row groups), ragged 8-row groups
+                                          (64, 9, 16, 512, 1, True), (7, 15, 24, 256, 2, False), (32, 10, 16, 128, 1, False),
+                                          (32, 17, 80, 512, 2, True)])
 def test_lstm_stack_fwd_bwd(B, T, I, H, L, bi):
     from rnntransducer_amd.networks.rnn import HipLSTM
     from rnntransducer_amd.ops import lstm_check, lstm_workspace
@@ -116,6 +120,14 @@ def test_lstm_v1_fallback_kernels_still_match(monkeypatch, B, T, I, H, L, bi):
     """The 128-workgroup-per-direction kernels (used when a shape does not fit the grouped v2 decomposition, e.g.
     H = 1024 with B > 16) stay covered: force them with RNNT_LSTM_V1=1."""
     monkeypatch.setenv("RNNT_LSTM_V1", "1")
+    test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
+
+
+@pytest.mark.parametrize("B,T,I,H,L,bi", [(32, 11, 16, 512, 1, True), (3, 12, 40, 640, 1, True), (64, 9, 16, 512, 1, True)])
+def test_lstm_v2_lds_resident_kernels_still_match(monkeypatch, B, T, I, H, L, bi):
+    """The v2 kernels (W_hh slice in LDS, f32-input 4x4x1 MFMA, gathered dG) remain the path for H = 1024 and other H not a
+    multiple of 128: keep them covered at the sizes the register-resident kernels normally take (RNNT_LSTM_V2=1)."""
+    monkeypatch.setenv("RNNT_LSTM_V2", "1")
     test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
 
 
