@@ -746,10 +746,10 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   else vec = vec && (d->b_sk % 4 == 0);
 
   const int mode = (d->flags & RNNT_GEMM_EXACT_F32) ? 0 : gemm_mode();
-  const int bks = (mode && getenv("RNNT_GEMM_BK32")) ? 32 : BK;  // K-tile depth 32 (128x128 tiles only): measured slower
-  const int bn = (mode && bks == 32) ? 128 : pick_bn(d->M, d->N);
+  const int bks = BK;  // (a K-tile depth of 32 with 128x128 tiles was measured slower: DESIGN.md 4.4; the kernel template still takes it)
+  const int bn = pick_bn(d->M, d->N);
   // 256x256 tiles / 512 threads / one workgroup per CU for the split-bf16 form when the output is large in both directions
-  const bool big = mode != 0 && bks == BK && d->M >= 256 && d->N >= 256 && !getenv("RNNT_GEMM_NO256");
+  const bool big = mode == 6 && d->M >= 256 && d->N >= 256 && !getenv("RNNT_GEMM_NO256");
   const int tiles = big ? (int)(ceil_div(d->M, 256) * ceil_div(d->N, 256)) : (int)(ceil_div(d->M, BM) * ceil_div(d->N, bn));
   const int slots = big ? 256 : 512;  // workgroups the chip holds at once
   // split-K when the output has too few tiles to fill 256 CUs and K is deep (weight-gradient GEMMs):
@@ -770,19 +770,13 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   k.slab = (float*)d->workspace;
   dim3 grid(tiles, splits), block(256);
   hipStream_t s = (hipStream_t)stream;
-  constexpr int LDS256_6 = 2 * 3 * (PlaneImg<256, BK>::BYTES * 2), LDS256_3 = 2 * 2 * (PlaneImg<256, BK>::BYTES * 2);
+  constexpr int LDS256_6 = 2 * 3 * (PlaneImg<256, BK>::BYTES * 2);
   ProfScope prof(RNNT_K_GEMM, 2.0 * (double)d->M * (double)d->N * (double)d->K, s);
 #define LAUNCH_BIG(AK, BKC, V)                                                                                          \
   do {                                                                                                                  \
-    if (mode == 6) {                                                                                                    \
-      RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16s256_kernel<AK, BKC, V, 6>,                              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_6));                        \
-      hipLaunchKernelGGL((gemm_bf16s256_kernel<AK, BKC, V, 6>), grid, dim3(512), LDS256_6, s, k);                       \
-    } else {                                                                                                            \
-      RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16s256_kernel<AK, BKC, V, 3>,                              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_3));                        \
-      hipLaunchKernelGGL((gemm_bf16s256_kernel<AK, BKC, V, 3>), grid, dim3(512), LDS256_3, s, k);                       \
-    }                                                                                                                   \
+    RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16s256_kernel<AK, BKC, V, 6>,                                \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_6));                          \
+    hipLaunchKernelGGL((gemm_bf16s256_kernel<AK, BKC, V, 6>), grid, dim3(512), LDS256_6, s, k);                         \
   } while (0)
 #define LAUNCH_K(KERNEL4, KERNEL2)                                        \
   do {                                                                    \
@@ -794,8 +788,6 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
     if (big) LAUNCH_BIG(AK, BKC, V);                                                                                    \
     else if (mode == 6 && bks == 16 && bn == 256 && splits == 1 && d->workspace && getenv("RNNT_GEMM_DBG"))             \
       hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 4, 6, 16, true>), grid, block, 0, s, k);                        \
-    else if (mode == 6 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 6, 32>), grid, block, 0, s, k);    \
-    else if (mode == 3 && bks == 32) hipLaunchKernelGGL((gemm_bf16s_kernel<AK, BKC, V, 2, 3, 32>), grid, block, 0, s, k); \
     else if (mode == 6) LAUNCH_K((gemm_bf16s_kernel<AK, BKC, V, 4, 6, 16>), (gemm_bf16s_kernel<AK, BKC, V, 2, 6, 16>)); \
     else if (mode == 3) LAUNCH_K((gemm_bf16s_kernel<AK, BKC, V, 4, 3, 16>), (gemm_bf16s_kernel<AK, BKC, V, 2, 3, 16>)); \
     else LAUNCH_K((gemm_f32_kernel<AK, BKC, V, 4>), (gemm_f32_kernel<AK, BKC, V, 2>));                                  \
