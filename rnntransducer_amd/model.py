@@ -93,6 +93,23 @@ class RNNTransducer(_Base):
             out["label_texts"] = tok.batch_decode([l.tolist() for l in labels])
         return out
 
+    def validation_epoch_end(self, validation_step_outputs):
+        """model.py:81-108: mean validation loss + error rates over the epoch's validation_step outputs.  WER/CER when the
+        steps carried texts (tokenizer attached), otherwise the token error rate on ids.  Returns the dict it logs."""
+        from .metrics import char_error_rate, token_error_rate, word_error_rate
+        out = {"val_loss": torch.stack([x["loss"].detach().reshape(()) for x in validation_step_outputs]).mean()}
+        if validation_step_outputs and "pred_texts" in validation_step_outputs[0]:
+            preds = [t for x in validation_step_outputs for t in x["pred_texts"]]
+            labels = [t for x in validation_step_outputs for t in x["label_texts"]]
+            out["val_wer"], out["val_cer"] = word_error_rate(preds, labels), char_error_rate(preds, labels)
+        else:
+            out["val_ter"] = token_error_rate([t for x in validation_step_outputs for t in x["pred_tokens"]],
+                                              [t for x in validation_step_outputs for t in x["label_tokens"]])
+        if pl is not None and getattr(self, "_trainer", None) is not None:
+            for k, v in out.items():
+                self.log(k, v.to(self.device) if isinstance(v, torch.Tensor) else v, sync_dist=True)
+        return out
+
     def configure_optimizers(self):
         group = [{"params": [p for p in self.parameters()], "name": "OneCycleLR"}]
         if next(self.parameters()).is_cuda:

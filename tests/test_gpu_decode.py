@@ -126,6 +126,8 @@ def test_validation_step_after_overfitting_one_batch_recovers_labels():
     out = model.validation_step(tuple(batch), 0)
     assert model.jointnet.training  # mode restored
     assert out["loss"].item() < 0.05
+    ep = model.validation_epoch_end([out, out])  # model.py:81-108: mean loss + error rate over the epoch's steps
+    assert abs(ep["val_loss"].item() - out["loss"].item()) < 1e-6 and 0.0 <= ep["val_ter"].item() <= 0.5
     from oracle.rnnt_oracle import OracleJointNet
     labels = [l.tolist() for l in out["label_tokens"]]
     # a greedy search need not follow the most probable alignment even at P(y|x) > 0.95 (emission mass may be spread
