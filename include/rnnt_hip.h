@@ -259,6 +259,21 @@ typedef struct rnnt_decode_desc {
 } rnnt_decode_desc;
 int rnnt_hip_greedy_decode(const rnnt_decode_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input side on device (datamodule.py:48-90, done offline on the host by the reference).
+ * rnnt_hip_frontend_norm_pad: per utterance b (row b of wav, lens[b] samples): optional mean / population-variance
+ *   normalisation (datamodule.py:87-90), reflect padding by `pad` samples at the utterance's own ends (torch.stft
+ *   center=True), zeros up to Lp.  out (B, Lp).
+ * The windowed DFT is then ONE rnnt_hip_gemm_f32 over the frames in place: M = B*F rows with a_div = F, a_so = Lp,
+ *   a_si = hop, K = n_fft, B = hann * [cos | -sin] basis (2*n_bins, n_fft).
+ * rnnt_hip_power_mel_log1p: spec (M, 2*n_bins) = [re | im] -> out (M, n_mels) = log1p(fb^T |X|^2), rows whose frame index
+ *   (m % frames_per_utt) is >= nframes[m / frames_per_utt] are written as 0 (the collate's pad value, dataloader.py:40).
+ * ---------------------------------------------------------------------------------------------- */
+int rnnt_hip_frontend_norm_pad(const float* wav, int64_t ld, const int32_t* lens, int32_t B, int32_t pad, int64_t Lp,
+                               int32_t normalize, float* out, void* stream);
+int rnnt_hip_power_mel_log1p(const float* spec, int64_t M, int32_t n_bins, const float* fb, int32_t n_mels,
+                             const int32_t* nframes, int32_t frames_per_utt, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

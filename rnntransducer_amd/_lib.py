@@ -87,6 +87,8 @@ SYMBOLS = {
     "rnnt_hip_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_embedding_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, c_i64, C.c_void_p, C.c_void_p]),
     "rnnt_hip_greedy_decode": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
+    "rnnt_hip_frontend_norm_pad": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i32, c_i32, c_i64, c_i32, C.c_void_p, C.c_void_p]),
+    "rnnt_hip_power_mel_log1p": (C.c_int, [C.c_void_p, c_i64, c_i32, C.c_void_p, c_i32, C.c_void_p, c_i32, C.c_void_p, C.c_void_p]),
 }
 
 KERNEL_KINDS = ["gemm_f32_kernel", "lstm_fwd_kernel", "lstm_bwd_kernel", "lse_kernel", "alphabeta_kernel",

@@ -46,3 +46,31 @@ def length_grouped_indices(lengths: Sequence[int], rank: int, world: int) -> Lis
     pad = (-len(order)) % world
     order = order + order[:pad]
     return order[rank::world]
+
+
+def collate_batch(batch, pad_token_id: int, n_mels: int):
+    """The 7-tuple of dataloader.py:16-49 from a list of samples {"input_values": (T_i, n_mels) float tensor,
+    "input_ids": label ids}: audio / texts / targets padded with pad_token_id, prediction-net input = [pad] + labels
+    (int64, as the reference's torch.cat promotes it), targets int32, python-list lengths for the packers and IntTensor
+    lengths for the loss."""
+    from torch.nn.utils.rnn import pad_sequence
+    input_audios = [s["input_values"] for s in batch]
+    audio_lengths = [int(a.size(0)) for a in input_audios]
+    targets = [torch.as_tensor(s["input_ids"], dtype=torch.int32) for s in batch]
+    target_lengths = torch.tensor([len(s["input_ids"]) for s in batch], dtype=torch.int32)
+    input_texts = [torch.cat([torch.full((1,), pad_token_id, dtype=torch.int64), t.to(torch.int64)]) for t in targets]
+    text_lengths = [int(t.numel()) for t in input_texts]
+    if input_audios[0].size(-1) != n_mels:
+        raise ValueError(f"feature width {input_audios[0].size(-1)} != n_mels {n_mels} (dataloader.py:38)")
+    return (pad_sequence(input_audios, batch_first=True, padding_value=pad_token_id), audio_lengths,
+            torch.tensor(audio_lengths, dtype=torch.int32), pad_sequence(input_texts, batch_first=True, padding_value=pad_token_id),
+            text_lengths, pad_sequence(targets, batch_first=True, padding_value=pad_token_id), target_lengths)
+
+
+class AudioDataLoader(torch.utils.data.DataLoader):
+    """dataloader.py:5-14: a DataLoader whose collate_fn emits the 7-tuple above."""
+
+    def __init__(self, pad_token_id, bos_token_id, n_mels, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.pad_token_id, self.bos_token_id, self.n_mels = pad_token_id, bos_token_id, n_mels
+        self.collate_fn = lambda batch: collate_batch(batch, self.pad_token_id, self.n_mels)

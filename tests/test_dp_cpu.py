@@ -92,3 +92,30 @@ def test_c4_global_batch_is_dealt_so_ranks_get_matching_length_profiles():
         assert max(col) - min(col) <= max(glob[i] - glob[j] for i in range(1) for j in range(1)) + (sorted(glob, reverse=True)[k * world] - sorted(glob, reverse=True)[k * world + world - 1])
     batch = synthetic_batch(B, T, 40, 72, t_lengths=shares[1], seed=5)
     assert batch[1] == shares[1] and all(1 <= u <= 40 for u in batch[6].tolist())
+
+
+def test_collate_matches_reference_fixture(golden_dir):
+    """data.collate_batch vs the 7-tuple the REFERENCE's AudioDataLoader._collate_fn produced on the same samples
+    (tests/golden/collate.npz, dataloader.py:16-49): values, shapes and dtypes."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from rnntransducer_amd.data import AudioDataLoader, collate_batch
+    g = dict(np.load(os.path.join(golden_dir, "collate.npz")))
+    n = len([k for k in g if k.endswith("/input_ids")])
+    samples = [{"input_values": torch.from_numpy(g[f"sample{i}/input_values"]), "input_ids": g[f"sample{i}/input_ids"].tolist()}
+               for i in range(n)]
+    out = collate_batch(samples, 0, 80)
+    names = ["input_audios", "audio_lengths", "tensor_audio_lengths", "input_texts", "text_lengths", "targets", "target_lengths"]
+    for name, v in zip(names, out):
+        want, dt = g["out/" + name], str(g["dtype/" + name])
+        if dt == "list":
+            assert isinstance(v, list) and v == want.tolist(), name
+        else:
+            assert str(v.dtype) == dt, (name, v.dtype, dt)
+            assert np.array_equal(v.numpy(), want), name
+    loader = AudioDataLoader(0, 1, 80, samples, batch_size=n)
+    again = next(iter(loader))
+    assert torch.equal(again[0], out[0]) and again[1] == out[1] and torch.equal(again[5], out[5])
