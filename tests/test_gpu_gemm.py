@@ -21,7 +21,9 @@ def gelu64(x):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (130, 70, 33), (257, 129, 80), (512, 256, 1024), (1000, 72, 512), (64, 2048, 640),
-                                   (37, 10, 16), (5, 3, 7), (2048, 1024, 96), (2100, 768, 40)])
+                                   (37, 10, 16), (5, 3, 7), (2048, 1024, 96), (2100, 768, 40),
+                                   # 256x256-tile kernel: unaligned K (scalar loads), exact tile, ragged edges
+                                   (300, 260, 33), (256, 256, 16), (515, 402, 400)])
 @pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
 def test_gemm_modes(M, N, K, mode):
     from rnntransducer_amd.ops import gemm
