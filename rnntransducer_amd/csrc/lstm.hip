@@ -62,6 +62,8 @@ struct LstmK {
   float* aux;      // GRU backward: hidden-side gate gradients (T,B,D,4H) for dW_hh / db_hh
   unsigned* xcc;   // v2: [D*G][NC] XCC id + 1 of every member, published once at kernel start (zeroed per launch)
   int allow_local; // v2: permit the L2-local exchange when a group is verified to sit on one XCD
+  float* dbp;      // v4 backward: (D*G*NBR, 4H) time sums of the input-side dG per exchange row, or nullptr
+  float* dbhp;     // same for the hidden-side dG (GRU)
   int NGL;         // v2+: launch stride of the group index (>= D*G): gid = blockIdx % NGL, blocks with gid >= D*G exit at once
   int hw_math;     // v2: v_exp_f32 / v_rcp_f32 cell math (default; measured whole-model loss delta identical to the ocml expf +
                    // IEEE-division form, which RNNT_LSTM_EXACT_MATH=1 selects)
@@ -1171,6 +1173,7 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
   const bool valid = owner && brow < p.Bg && ob < B;
   const int olen = valid ? p.lens[ob] : 0;
   float dc_carry = 0.f;
+  f32x4 db_acc = {0.f, 0.f, 0.f, 0.f}, dbh_acc = {0.f, 0.f, 0.f, 0.f};  // bias gradients: time sums of this cell's dG
   const int t_first = (d == 0) ? T - 1 : 0;
   const long tdir = (d == 0) ? -1 : 1;
   long g_off = (((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj;
@@ -1265,6 +1268,8 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
       } else {
         dc_carry = 0.f;
       }
+      db_acc += dg4;
+      if constexpr (CELL == 1) dbh_acc += dgh4;
       *reinterpret_cast<f32x4*>(&dgs[brow * DGS_LD + 4 * (4 * ouq + oi)]) = dgh4;  // own gate column 4*unit + gate
     }
     __syncthreads();
@@ -1306,6 +1311,11 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
   };
   const bool ok = local ? run(std::true_type{}) : run(std::false_type{});
   if (!ok) return;
+  if (owner) {  // one row of the (group, exchange row) table per cell row; summed over rows and groups by db_reduce_kernel
+    const long row = (long)gid * NBR + brow;
+    *reinterpret_cast<f32x4*>(p.dbp + row * 4 * H + 4 * oj) = db_acc;
+    if constexpr (CELL == 1) *reinterpret_cast<f32x4*>(p.dbhp + row * 4 * H + 4 * oj) = dbh_acc;
+  }
   if (p.dbg && tid == 0) {
     for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
     unsigned xcc_id;
@@ -1318,6 +1328,16 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
+// db[d][g*H + j] = sum over the direction's (group, row) table of part[(d*rows_per_dir + r)*4H + 4j+g], fixed order
+__global__ void db_reduce_kernel(const float* __restrict__ part, int rows_per_dir, int H, int ngate, float* __restrict__ o0,
+                                 float* __restrict__ o1) {
+  const int c = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
+  if (c >= 4 * H || (c & 3) >= ngate) return;
+  const float* src = part + (long)d * rows_per_dir * 4 * H + c;
+  float s = 0.f;
+  for (int r = 0; r < rows_per_dir; ++r) s += src[(long)r * 4 * H];
+  (d ? o1 : o0)[(c & 3) * H + (c >> 2)] = s;
+}
 // out[(d*4H + 4j+g)*I + k] = g < ngate ? w[d][(g*H + j)*I + k] : 0      (4 slots per unit whatever the cell type)
 __global__ void permute_w_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int H, int I, int ngate,
                                  float* __restrict__ out) {
@@ -1439,6 +1459,8 @@ struct LstmWs {
   float* bp;   // (D*4H)
   float* dwhh; // (D*4H, H) scratch for dW_hh'
   unsigned long long* dbg;  // 256 workgroups x 8 phase counters (diagnostics)
+  float* dbp;   // v4 backward: per-(group, row) time sums of dG (input side | hidden side), (2, D*G*NBR, 4H)
+  size_t dbp_half;  // floats per side
   void* scratch;  // split-K slabs of the weight-gradient GEMMs / column-sum partials
   size_t scratch_bytes;
   size_t total;
@@ -1569,6 +1591,8 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
   w.bp = reinterpret_cast<float*>(take((size_t)D * 4 * H * 4));
   w.dwhh = reinterpret_cast<float*>(take((size_t)D * 4 * H * H * 4));
   w.dbg = reinterpret_cast<unsigned long long*>(take(512 * 8 * 8));
+  w.dbp_half = (size_t)D * (B + 64) * 4 * H;  // D*G*NBR <= D*(B + 4*G) rows of 4H
+  w.dbp = reinterpret_cast<float*>(take(2 * w.dbp_half * 4));
   {
     const int64_t M = (int64_t)T * B, N4 = (int64_t)D * 4 * H;
     size_t sc = rnnt_hip_gemm_workspace_bytes(N4, I, M);
@@ -1691,6 +1715,7 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->b_hh[0] = d->b_hh[0]; k->b_hh[1] = d->D > 1 ? d->b_hh[1] : d->b_hh[0];
   k->aux = d->aux;
   k->G = 1; k->Bg = d->B; k->Kp = d->H; k->NGL = d->D;
+  k->dbp = w.dbp; k->dbhp = w.dbp + w.dbp_half;
   k->dbg = getenv("RNNT_LSTM_DBG") ? w.dbg : nullptr;
   k->xcc = w.flags + 16 + w.nflags;
   k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
@@ -1838,8 +1863,12 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     k.NC = q.NC; k.Hs = q.HS; k.G = q.G; k.Bg = q.Bg; k.Kp = q.Kp;
     k.NGL = group_launch_stride(d->D * q.G, q.NC, cus);
   };
+  bool fused_db = false;
+  int db_rows = 0;
   if (make_plan3(d->B, d->H, d->D, cus, true, &p2)) {
     adopt(p2);
+    fused_db = true;
+    db_rows = p2.G * 4 * p2.BQ;
     const int nks = p2.Kp / 128;
 #define LAUNCH_V4_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<N, BQ_, C>, k, p2, p2.lds_bwd, s, "lstm_bwd4")
 #define LAUNCH_V4_B(N, C)                           \
@@ -1922,8 +1951,17 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
                        bd->dw_hh[0], D > 1 ? bd->dw_hh[1] : bd->dw_hh[0]);
     RNNT_CHECK_LAUNCH();
   }
-  // 5. bias gradient = column sums of dG, un-permuted
-  {
+  // 5. bias gradient = column sums of dG, un-permuted (the v4 recurrence already summed its own cells over time)
+  if (fused_db) {
+    hipLaunchKernelGGL(db_reduce_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, k.dbp, db_rows, H, ngate, bd->db[0],
+                       D > 1 ? bd->db[1] : bd->db[0]);
+    RNNT_CHECK_LAUNCH();
+    if (gru) {
+      hipLaunchKernelGGL(db_reduce_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, k.dbhp, db_rows, H, ngate, bd->db_hh[0],
+                         D > 1 ? bd->db_hh[1] : bd->db_hh[0]);
+      RNNT_CHECK_LAUNCH();
+    }
+  } else {
     if ((rc = launch_colsum(d->gates, (long)M, (long)N4, (long)N4, w.bp, w.scratch, w.scratch_bytes, s))) return rc;
     hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, w.bp, H, 1, (long)4 * H, ngate,
                        bd->db[0], D > 1 ? bd->db[1] : bd->db[0]);
