@@ -1552,10 +1552,6 @@ bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
   return true;
 }
 
-// launch stride of the group index: 8 (= XCDs) when the groups fit one XCD each, so that the round-robin block -> XCD
-// placement puts all members of a group on one XCD (L2-local exchange); blocks of the unused group slots exit at once
-inline int group_launch_stride(int NG, int NC, int cus) { return (NG <= 8 && NC * 8 <= cus) ? 8 : NG; }
-
 LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
   LstmWs w;
   char* p = reinterpret_cast<char*>(ws);
@@ -1630,15 +1626,22 @@ int launch_persistent(K kernel, const LstmK& k, const Plan& pl, size_t lds, hipS
 }
 
 template <typename K>
-int launch_persistent2(K kernel, const LstmK& k, const Plan2& pl, size_t lds, hipStream_t s, const char* what) {
+int launch_persistent2(K kernel, const LstmK& k_in, const Plan2& pl, size_t lds, hipStream_t s, const char* what) {
   if (lds > 64 * 1024)
     RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
   RNNT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
   const int cus = device_cus();
-  const int active = k.D * pl.G * pl.NC;   // workgroups that take part (must be co-resident)
-  const int grid = k.NGL * pl.NC;          // launched: the idle group slots of an XCD-aligned launch exit immediately
-  if (per_cu < 1 || active > cus) {
+  LstmK k = k_in;
+  const int NG = k.D * pl.G;
+  // Launch stride of the group index: 8 (= XCDs) when every group fits one XCD, so that the round-robin block -> XCD placement
+  // puts all members of a group on one XCD (L2-local exchange); blocks of the unused group slots exit at once.  A group of
+  // more than 32 members fits an XCD only if this kernel's resources let two workgroups share a CU (register-form kernels).
+  const int fit = (per_cu < 2 ? per_cu : 2) * (cus / 8);
+  k.NGL = (NG <= 8 && pl.NC <= fit && !getenv("RNNT_LSTM_NO_XCD_STRIDE")) ? 8 : NG;
+  const int active = NG * pl.NC;   // workgroups that take part (must be co-resident)
+  const int grid = k.NGL * pl.NC;  // launched
+  if (per_cu < 1 || active > cus * (k.NGL == 8 && pl.NC > cus / 8 ? 2 : 1)) {
     set_error("%s: %d workgroups cannot be co-resident (%d CUs x %d per CU)", what, active, cus, per_cu);
     return RNNT_ERR_UNSUPPORTED;
   }
@@ -1805,7 +1808,6 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   const int cus = device_cus();
   auto adopt = [&](const Plan2& q) {
     k.NC = q.NC; k.Hs = q.HS; k.G = q.G; k.Bg = q.Bg; k.Kp = q.Kp;
-    k.NGL = group_launch_stride(d->D * q.G, q.NC, cus);
   };
   if (make_plan3(d->B, d->H, d->D, cus, false, &p2)) {
     adopt(p2);
@@ -1861,7 +1863,6 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   const int cus = device_cus();
   auto adopt = [&](const Plan2& q) {
     k.NC = q.NC; k.Hs = q.HS; k.G = q.G; k.Bg = q.Bg; k.Kp = q.Kp;
-    k.NGL = group_launch_stride(d->D * q.G, q.NC, cus);
   };
   bool fused_db = false;
   int db_rows = 0;
