@@ -758,15 +758,15 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
 // Stash layouts (gates, cst, y) are those of v2, so lstm_bwd2_kernel consumes them unchanged.
 // dynamic LDS: part[4 waves][4 mb][64] f32x4 | abort
 // ================================================================================================
-template <int NKS, int CELL>
-__global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
+template <int NKS, int CELL, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
   constexpr int HS = 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
   constexpr int Kw = 32 * NKS;
   f32x4* part = reinterpret_cast<f32x4*>(smem);
-  int* abort_lds = reinterpret_cast<int*>(part + 16 * 64);
+  int* abort_lds = reinterpret_cast<int*>(part + NWV * 4 * 64);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = D * p.G;
@@ -810,14 +810,16 @@ __global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
                                                      (int)hx_bytes, RSRC_FLAGS);
   unsigned* flags = p.flags + gid * p.NC;
 
-  // one cell per lane: unit 4*wave + lq of this workgroup, batch row lrow of this group
+  // one cell per lane of waves 0..3: unit 4*wave + lq of this workgroup, batch row lrow of this group (with NWV = 8 the
+  // upper four waves only contribute their K-slice of the product)
+  const bool ownw = wave < 4;
   const int brow = lrow;
-  const int ob = b0 + brow, oj = j0 + 4 * wave + lq;
-  const bool inrow = brow < NBR;
-  const bool valid = brow < p.Bg && ob < B;
+  const int ob = b0 + brow, oj = j0 + 4 * (wave & 3) + lq;
+  const bool inrow = ownw && brow < NBR;
+  const bool valid = ownw && brow < p.Bg && ob < B;
   const int olen = valid ? p.lens[ob] : 0;
   float c_state = 0.f;
-  const float bhn = (CELL == 1) ? p.b_hh[d][2 * H + oj] : 0.f;
+  const float bhn = (CELL == 1 && ownw) ? p.b_hh[d][2 * H + oj] : 0.f;
   const int t_first = (d == 0) ? 0 : T - 1;
   const long tdir = (d == 0) ? 1 : -1;
   long g_off = (((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj;
@@ -825,7 +827,7 @@ __global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
   long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
   const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
   const int hx_off = (brow * Kp + oj) * 2;
-  const int gat_off = inrow ? (brow * Kp + wave * Kw + 8 * lq) * 2 : 0x7ffffff0;  // rows beyond the group read 0
+  const int gat_off = brow < NBR ? (brow * Kp + wave * Kw + 8 * lq) * 2 : 0x7ffffff0;  // rows beyond the group read 0
   __syncthreads();
   unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
   const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
@@ -870,9 +872,9 @@ __global__ void __launch_bounds__(256) lstm_fwd3_kernel(const LstmK p) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) part[(wave * 4 + mb) * 64 + lane] = acc[mb];
     __syncthreads();
-    f32x4 rec = part[wave * 64 + lane];
+    f32x4 rec = part[(wave & 3) * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) rec += part[(w * 4 + wave) * 64 + lane];
+    for (int w = 1; w < NWV; ++w) rec += part[(w * 4 + (wave & 3)) * 64 + lane];
     const bool active = valid && t < olen;
     float hval = 0.f;
     f32x4 gact = {0.f, 0.f, 0.f, 0.f};
@@ -1113,17 +1115,18 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
 // Exchange buffer: partial[parity][group][producer][row][Kp] fp32.  Protocol, owners, cell math and stash as in v2.
 // dynamic LDS: red[256] f32x4 | dgs[16][DGS_LD] float | abort
 // ================================================================================================
-template <int NKS, int BQ, int CELL>
-__global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
+template <int NKS, int BQ, int CELL, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
   constexpr int HS = 16, UQ = 4;
-  constexpr int NMB = 2 * NKS;          // 16-unit output blocks per wave: Kp/64 with Kp = 128*NKS
+  constexpr int NT = 64 * NWV;
+  constexpr int NMB = 8 * NKS / NWV;    // 16-unit output blocks per wave: (Kp/16)/NWV with Kp = 128*NKS
   constexpr int NBR = 4 * BQ;           // exchange rows of the group
   constexpr int DGS_LD = 68;            // floats per row of the dG image (64 + pad)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
   f32x4* red = reinterpret_cast<f32x4*>(smem);
-  float* dgs = reinterpret_cast<float*>(red + 256);
+  float* dgs = reinterpret_cast<float*>(red + NT);
   int* abort_lds = reinterpret_cast<int*>(dgs + 16 * DGS_LD);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1156,7 +1159,7 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
         split8(lo, hi, wp[mb][ks]);
       }
     }
-    for (int i = tid; i < 16 * DGS_LD; i += 256) dgs[i] = 0.f;
+    for (int i = tid; i < 16 * DGS_LD; i += NT) dgs[i] = 0.f;
     if (tid == 0) *abort_lds = 0;
   }
   const long px_floats = (long)p.NC * NBR * Kp;  // one group's partials of one parity
@@ -1180,11 +1183,11 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
   long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3);
   long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
   const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
-  // gather: item idx = tid + 256*i -> (unit quad idx&3, row (idx>>2) % NBR, producer idx / (4*NBR)); 4*NBR divides 256, so a
+  // gather: item idx = tid + NT*i -> (unit quad idx&3, row (idx>>2) % NBR, producer idx / (4*NBR)); 4*NBR divides NT, so a
   // thread always meets the same (row, quad) and sums over the producers it visits
   const int grow = (tid >> 2) % NBR, guq = tid & 3;
-  const int gat_base = ((tid / (4 * NBR)) * NBR + grow) * Kp + j0 + 4 * guq;  // floats; + 256/(4*NBR) producers per i
-  const int gat_step = (256 / (4 * NBR)) * NBR * Kp;
+  const int gat_base = ((tid / (4 * NBR)) * NBR + grow) * Kp + j0 + 4 * guq;  // floats; + NT/(4*NBR) producers per i
+  const int gat_step = (NT / (4 * NBR)) * NBR * Kp;
   const int nitems = p.NC * NBR * 4;
   // publish: lane -> row lrow, units 16*mbg + 4*lq .. +3
   const int pub_base = lrow < NBR ? ((wg * NBR + lrow) * Kp + 16 * wave * NMB + 4 * lq) * 4 : 0x7ffffff0;
@@ -1219,11 +1222,11 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
       DBG_STAMP(1);  // flag wait
       const __amdgpu_buffer_rsrc_t src = px_rsrc[(s - 1) & 1];
       constexpr int NI = 4;
-      for (int i0 = 0; i0 * 256 < nitems; i0 += NI) {
+      for (int i0 = 0; i0 * NT < nitems; i0 += NI) {
         i32x4 r[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          const bool ok = (i0 + i) * 256 + tid < nitems;
+          const bool ok = (i0 + i) * NT + tid < nitems;
           r[i] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? (gat_base + (i0 + i) * gat_step) * 4 : 0x7ffffff0, 0, AUX_SC1);
         }
 #pragma unroll
@@ -1236,7 +1239,7 @@ __global__ void __launch_bounds__(256) lstm_bwd4_kernel(const LstmK p) {
     f32x4 dg4 = {0.f, 0.f, 0.f, 0.f}, dgh4 = {0.f, 0.f, 0.f, 0.f};
     if (owner) {
       float dh = dyv;
-      constexpr int NQ = 256 / (4 * NBR);
+      constexpr int NQ = NT / (4 * NBR);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) dh += red[q * 4 * NBR + brow * 4 + ouq][oi];
       if (active) {
@@ -1537,7 +1540,9 @@ bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
   if (H % 128 != 0 || B < 1 || D < 1 || D > 2) return false;
   const int nks = H / 128;
   (void)bwd;
-  if (!(nks == 1 || nks == 2 || nks == 4 || nks == 5)) return false;  // H = 1024 (8 k-steps) lives off AGPR copies / spills: measured slower than v2
+  // H = 1024: 8 waves per workgroup, each with the operand registers of the H = 512 / 4-wave form (4 waves would need 384
+  // operand registers per lane: measured slower than v2)
+  if (!(nks == 1 || nks == 2 || nks == 4 || nks == 5 || nks == 8) || (nks == 8 && getenv("RNNT_LSTM_NO_8WAVE"))) return false;
   const int NC = H / 16;
   const int Gmax = cus / (D * NC);
   if (Gmax < 1) return false;
@@ -1547,8 +1552,9 @@ bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
   if (Bg > 16) return false;
   G = (int)ceil_div(B, Bg);
   pl->HS = 16; pl->NC = NC; pl->G = G; pl->Bg = Bg; pl->BQ = Bg <= 4 ? 1 : (Bg <= 8 ? 2 : 4); pl->Kp = H;
-  pl->lds_fwd = 16 * 64 * 16 + 16;
-  pl->lds_bwd = 256 * 16 + 16 * 68 * 4 + 16;
+  const int nwv = nks == 8 ? 8 : 4;
+  pl->lds_fwd = (size_t)nwv * 4 * 64 * 16 + 16;
+  pl->lds_bwd = (size_t)nwv * 64 * 16 + 16 * 68 * 4 + 16;
   return true;
 }
 
@@ -1626,11 +1632,11 @@ int launch_persistent(K kernel, const LstmK& k, const Plan& pl, size_t lds, hipS
 }
 
 template <typename K>
-int launch_persistent2(K kernel, const LstmK& k_in, const Plan2& pl, size_t lds, hipStream_t s, const char* what) {
+int launch_persistent2(K kernel, const LstmK& k_in, const Plan2& pl, size_t lds, hipStream_t s, const char* what, int threads = 256) {
   if (lds > 64 * 1024)
     RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
-  RNNT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
+  RNNT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
   const int cus = device_cus();
   LstmK k = k_in;
   const int NG = k.D * pl.G;
@@ -1648,7 +1654,7 @@ int launch_persistent2(K kernel, const LstmK& k_in, const Plan2& pl, size_t lds,
   {
     const double per_tb = (k.dy ? (8.0 + 2.0 + 1.0) : (8.0 + 1.0 + 1.0)) * k.H * 4.0;
     ProfScope prof(k.dy ? RNNT_K_LSTM_BWD : RNNT_K_LSTM_FWD, per_tb * k.T * k.B * k.D + 4.0 * 4.0 * k.H * k.H * k.D, s);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, s, k);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, k);
   }
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
@@ -1821,7 +1827,12 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
     if (nks == 1) LAUNCH_V3(1);
     else if (nks == 2) LAUNCH_V3(2);
     else if (nks == 4) LAUNCH_V3(4);
-    else LAUNCH_V3(5);
+    else if (nks == 5) LAUNCH_V3(5);
+    else {  // H = 1024: 8 waves x 4 k-steps
+      if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<4, 0, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+      else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<4, 1, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+      else rc = launch_persistent2(lstm_fwd3_kernel<4, 2, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+    }
 #undef LAUNCH_V3
   } else if (make_plan2(d->B, d->H, d->D, cus, &p2)) {
     adopt(p2);
@@ -1887,7 +1898,21 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     if (nks == 1) LAUNCH_V4(1);
     else if (nks == 2) LAUNCH_V4(2);
     else if (nks == 4) LAUNCH_V4(4);
-    else LAUNCH_V4(5);
+    else if (nks == 5) LAUNCH_V4(5);
+    else {  // H = 1024: 8 waves, 8 output blocks each
+#define LAUNCH_V48_C(BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<8, BQ_, C, 8>, k, p2, p2.lds_bwd, s, "lstm_bwd4", 512)
+#define LAUNCH_V48_B(C)                           \
+      do {                                        \
+        if (p2.BQ == 1) LAUNCH_V48_C(1, C);       \
+        else if (p2.BQ == 2) LAUNCH_V48_C(2, C);  \
+        else LAUNCH_V48_C(4, C);                  \
+      } while (0)
+      if (d->cell == RNNT_CELL_LSTM) LAUNCH_V48_B(0);
+      else if (d->cell == RNNT_CELL_GRU) LAUNCH_V48_B(1);
+      else LAUNCH_V48_B(2);
+#undef LAUNCH_V48_B
+#undef LAUNCH_V48_C
+    }
 #undef LAUNCH_V4
 #undef LAUNCH_V4_B
 #undef LAUNCH_V4_C
