@@ -127,8 +127,8 @@ def test_lstm_v1_fallback_kernels_still_match(monkeypatch, B, T, I, H, L, bi):
 
 @pytest.mark.parametrize("B,T,I,H,L,bi", [(32, 11, 16, 512, 1, True), (3, 12, 40, 640, 1, True), (64, 9, 16, 512, 1, True)])
 def test_lstm_v2_lds_resident_kernels_still_match(monkeypatch, B, T, I, H, L, bi):
-    """The v2 kernels (W_hh slice in LDS, f32-input 4x4x1 MFMA, gathered dG) remain the path for H = 1024 and other H not a
-    multiple of 128: keep them covered at the sizes the register-resident kernels normally take (RNNT_LSTM_V2=1)."""
+    """The v2 kernels (W_hh slice in LDS, f32-input 4x4x1 MFMA, gathered dG) remain the path for every H outside
+    {128, 256, 512, 640, 1024}: keep them covered at the sizes the register-resident kernels normally take (RNNT_LSTM_V2=1)."""
     monkeypatch.setenv("RNNT_LSTM_V2", "1")
     test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
 
