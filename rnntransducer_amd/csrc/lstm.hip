@@ -1542,7 +1542,9 @@ bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
   (void)bwd;
   // H = 1024: 8 waves per workgroup, each with the operand registers of the H = 512 / 4-wave form (4 waves would need 384
   // operand registers per lane: measured slower than v2)
-  if (!(nks == 1 || nks == 2 || nks == 4 || nks == 5 || nks == 8) || (nks == 8 && getenv("RNNT_LSTM_NO_8WAVE"))) return false;
+  // H = 768: 8 waves x 3 k-steps
+  if (!(nks >= 1 && nks <= 6) && nks != 8) return false;
+  if (nks >= 6 && getenv("RNNT_LSTM_NO_8WAVE")) return false;
   const int NC = H / 16;
   const int Gmax = cus / (D * NC);
   if (Gmax < 1) return false;
@@ -1552,7 +1554,7 @@ bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
   if (Bg > 16) return false;
   G = (int)ceil_div(B, Bg);
   pl->HS = 16; pl->NC = NC; pl->G = G; pl->Bg = Bg; pl->BQ = Bg <= 4 ? 1 : (Bg <= 8 ? 2 : 4); pl->Kp = H;
-  const int nwv = nks == 8 ? 8 : 4;
+  const int nwv = nks >= 6 ? 8 : 4;
   pl->lds_fwd = (size_t)nwv * 4 * 64 * 16 + 16;
   pl->lds_bwd = (size_t)nwv * 64 * 16 + 16 * 68 * 4 + 16;
   return true;
@@ -1826,12 +1828,19 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
     } while (0)
     if (nks == 1) LAUNCH_V3(1);
     else if (nks == 2) LAUNCH_V3(2);
+    else if (nks == 3) LAUNCH_V3(3);
     else if (nks == 4) LAUNCH_V3(4);
     else if (nks == 5) LAUNCH_V3(5);
-    else {  // H = 1024: 8 waves x 4 k-steps
-      if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<4, 0, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
-      else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<4, 1, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
-      else rc = launch_persistent2(lstm_fwd3_kernel<4, 2, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+    else {  // H = 768 / 1024: 8 waves x 3 / 4 k-steps
+#define LAUNCH_V38(N)                                                                                                       \
+      do {                                                                                                                  \
+        if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<N, 0, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512); \
+        else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512); \
+        else rc = launch_persistent2(lstm_fwd3_kernel<N, 2, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);                     \
+      } while (0)
+      if (nks == 6) LAUNCH_V38(3);
+      else LAUNCH_V38(4);
+#undef LAUNCH_V38
     }
 #undef LAUNCH_V3
   } else if (make_plan2(d->B, d->H, d->D, cus, &p2)) {
@@ -1897,19 +1906,26 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     } while (0)
     if (nks == 1) LAUNCH_V4(1);
     else if (nks == 2) LAUNCH_V4(2);
+    else if (nks == 3) LAUNCH_V4(3);
     else if (nks == 4) LAUNCH_V4(4);
     else if (nks == 5) LAUNCH_V4(5);
-    else {  // H = 1024: 8 waves, 8 output blocks each
-#define LAUNCH_V48_C(BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<8, BQ_, C, 8>, k, p2, p2.lds_bwd, s, "lstm_bwd4", 512)
-#define LAUNCH_V48_B(C)                           \
-      do {                                        \
-        if (p2.BQ == 1) LAUNCH_V48_C(1, C);       \
-        else if (p2.BQ == 2) LAUNCH_V48_C(2, C);  \
-        else LAUNCH_V48_C(4, C);                  \
+    else {  // H = 768 / 1024: 8 waves, 6 / 8 output blocks each
+#define LAUNCH_V48_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<N, BQ_, C, 8>, k, p2, p2.lds_bwd, s, "lstm_bwd4", 512)
+#define LAUNCH_V48_B(N, C)                           \
+      do {                                           \
+        if (p2.BQ == 1) LAUNCH_V48_C(N, 1, C);       \
+        else if (p2.BQ == 2) LAUNCH_V48_C(N, 2, C);  \
+        else LAUNCH_V48_C(N, 4, C);                  \
       } while (0)
-      if (d->cell == RNNT_CELL_LSTM) LAUNCH_V48_B(0);
-      else if (d->cell == RNNT_CELL_GRU) LAUNCH_V48_B(1);
-      else LAUNCH_V48_B(2);
+#define LAUNCH_V48(N)                                          \
+      do {                                                     \
+        if (d->cell == RNNT_CELL_LSTM) LAUNCH_V48_B(N, 0);     \
+        else if (d->cell == RNNT_CELL_GRU) LAUNCH_V48_B(N, 1); \
+        else LAUNCH_V48_B(N, 2);                               \
+      } while (0)
+      if (nks == 6) LAUNCH_V48(6);
+      else LAUNCH_V48(8);
+#undef LAUNCH_V48
 #undef LAUNCH_V48_B
 #undef LAUNCH_V48_C
     }

@@ -29,7 +29,8 @@ def _oracle(x, lens, ref, dy):
                                           (64, 9, 16, 512, 1, True), (7, 15, 24, 256, 2, False), (32, 10, 16, 128, 1, False),
                                           (32, 17, 80, 512, 2, True),
                                           # H = 1024 (the shipped config.json size): 8-wave register-form kernels
-                                          (16, 6, 24, 1024, 1, True), (5, 4, 8, 1024, 2, False)])
+                                          (16, 6, 24, 1024, 1, True), (5, 4, 8, 1024, 2, False),
+                                          (6, 7, 16, 384, 1, True), (9, 5, 16, 768, 1, True)])
 def test_lstm_stack_fwd_bwd(B, T, I, H, L, bi):
     from rnntransducer_amd.networks.rnn import HipLSTM
     from rnntransducer_amd.ops import lstm_check, lstm_workspace
@@ -168,7 +169,7 @@ def test_xcd_local_exchange_is_bitwise_identical_to_write_through(monkeypatch):
 
 @pytest.mark.parametrize("cell", ["gru", "rnn_tanh", "rnn_relu"])
 @pytest.mark.parametrize("B,T,I,H,L,bi", [(1, 1, 4, 4, 1, False), (3, 7, 5, 8, 2, True), (5, 20, 80, 16, 2, True), (17, 9, 8, 32, 1, True),
-                                          (32, 11, 16, 512, 1, True), (4, 14, 24, 640, 1, True), (16, 5, 16, 1024, 1, True)])
+                                          (32, 11, 16, 512, 1, True), (4, 14, 24, 640, 1, True), (16, 5, 16, 1024, 1, True), (9, 5, 16, 768, 1, True)])
 def test_gru_and_elman_cells_fwd_bwd(cell, B, T, I, H, L, bi):
     """the reference's other supported_rnns (encoder.py:48-52) on the same persistent kernels, against
     torch.nn.GRU / torch.nn.RNN on the CPU in float64 over a PackedSequence."""
