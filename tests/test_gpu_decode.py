@@ -141,3 +141,15 @@ def test_validation_step_after_overfitting_one_batch_recovers_labels():
     want, margin = ora.recognize_greedy(batch[0].cpu(), batch[1], 0, 3, return_margin=True)
     if margin >= 1e-4:
         assert [p.tolist() for p in out["pred_tokens"]] == want
+
+
+def test_synthetic_pipeline_example_learns():
+    """examples/pipeline_synthetic.py: front-end -> collate -> training steps -> validation (greedy search) on the GPU."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "pipeline_synthetic.py")
+    spec = importlib.util.spec_from_file_location("pipeline_synthetic", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    first, last, ep = mod.main(["--steps", "60", "--batch", "4", "--seconds", "1.2"])
+    assert last < 0.5 * first and 0.0 <= ep["val_ter"].item() <= 1.5
