@@ -217,7 +217,9 @@ def main():
     out = {
         "metric": "utterances/sec", "value": round(world * B * a.steps / dt, 3), "unit": "utt/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "gemm_arithmetic": gemm_mode, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "gemm_arithmetic": gemm_mode,
+        "recurrence_arithmetic": "f32 MFMA (v2 kernels)" if os.environ.get("RNNT_LSTM_V2") else "bf16x6 (exact 3-way operand split, 6 products, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"{'BASELINE configs[%d]' % (list(CONFIGS).index(a.config) + (1 if a.config == 'c5' else 0)) if a.config != 'shipped' else 'reference config.json'} {a.config}: full train step, B={B}/GPU T={T} "
                                f"(10 ms frames x 80 mel) U={U} V={V}, enc {cfg[4][1]}x{cfg[4][0]} bi-{tn['rnn_type'].upper()}, pred {cfg[5][1]}x{cfg[5][0]} {pn['rnn_type'].upper()}, "
                                f"O={cfg[6]}, dropout {a.dropout}, {'ragged' if a.ragged else 'fixed'} lengths",
