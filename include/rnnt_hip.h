@@ -259,6 +259,24 @@ typedef struct rnnt_decode_desc {
 } rnnt_decode_desc;
 int rnnt_hip_greedy_decode(const rnnt_decode_desc* d, void* stream);
 
+/* One prediction-net step for a batch with carried state (networks/decoder.py:121-123: `self.rnn(embedded,
+ * prev_hidden_state)` on a (B,1) token column, as the reference's search loops call it).  h_in / c_in (L,B,Hp) may be NULL
+ * (= zeros: prev_hidden_state None); h_out / c_out (L,B,Hp); the layer output is h_out[L-1].  c_* only for LSTM. */
+typedef struct rnnt_prednet_step_desc {
+  int32_t B, Hp, L, cell;
+  const int64_t* tokens; /* (B) */
+  const float* emb;      /* (V,Hp) */
+  const float* w_ih[RNNT_DECODE_MAX_LAYERS];
+  const float* w_hh[RNNT_DECODE_MAX_LAYERS];
+  const float* b_ih[RNNT_DECODE_MAX_LAYERS];
+  const float* b_hh[RNNT_DECODE_MAX_LAYERS];
+  const float* h_in;
+  const float* c_in;
+  float* h_out;
+  float* c_out;
+} rnnt_prednet_step_desc;
+int rnnt_hip_prednet_step(const rnnt_prednet_step_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input side on device (datamodule.py:48-90, done offline on the host by the reference).
  * rnnt_hip_frontend_norm_pad: per utterance b (row b of wav, lens[b] samples): optional mean / population-variance

@@ -53,6 +53,13 @@ class DecodeDesc(C.Structure):
                 ("tokens", C.c_void_p), ("ntok", C.c_void_p)]
 
 
+class PrednetStepDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("Hp", c_i32), ("L", c_i32), ("cell", c_i32), ("tokens", C.c_void_p), ("emb", C.c_void_p),
+                ("w_ih", C.c_void_p * DECODE_MAX_LAYERS), ("w_hh", C.c_void_p * DECODE_MAX_LAYERS),
+                ("b_ih", C.c_void_p * DECODE_MAX_LAYERS), ("b_hh", C.c_void_p * DECODE_MAX_LAYERS),
+                ("h_in", C.c_void_p), ("c_in", C.c_void_p), ("h_out", C.c_void_p), ("c_out", C.c_void_p)]
+
+
 # every symbol include/rnnt_hip.h declares: (name, restype, argtypes)
 SYMBOLS = {
     "rnnt_hip_version": (C.c_int, []),
@@ -87,6 +94,7 @@ SYMBOLS = {
     "rnnt_hip_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_embedding_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, c_i64, C.c_void_p, C.c_void_p]),
     "rnnt_hip_greedy_decode": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
+    "rnnt_hip_prednet_step": (C.c_int, [C.POINTER(PrednetStepDesc), C.c_void_p]),
     "rnnt_hip_frontend_norm_pad": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i32, c_i32, c_i64, c_i32, C.c_void_p, C.c_void_p]),
     "rnnt_hip_power_mel_log1p": (C.c_int, [C.c_void_p, c_i64, c_i32, C.c_void_p, c_i32, C.c_void_p, c_i32, C.c_void_p, C.c_void_p]),
 }

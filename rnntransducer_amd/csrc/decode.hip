@@ -181,6 +181,73 @@ __global__ void __launch_bounds__(DEC_THREADS) greedy_decode_kernel(const Decode
   if (tid == 0) p.ntok[b] = n < p.max_out ? n : p.max_out;
 }
 
+
+// One prediction-net step for a batch (networks/decoder.py:121-123: `self.rnn(embedded, prev_hidden_state)` on a (B,1) token
+// column): one workgroup per batch row, state through LDS, same matvec / cell code as the search kernel.
+struct StepK {
+  int B, Hp, L, cell;
+  const long long* tokens;  // (B)
+  const float* emb;
+  const float* w_ih[DEC_MAX_LAYERS];
+  const float* w_hh[DEC_MAX_LAYERS];
+  const float* b_ih[DEC_MAX_LAYERS];
+  const float* b_hh[DEC_MAX_LAYERS];
+  const float* h_in;  // (L,B,Hp) or null (zeros)
+  const float* c_in;  // LSTM only; or null
+  float* h_out;       // (L,B,Hp)
+  float* c_out;       // LSTM only
+};
+
+__global__ void __launch_bounds__(DEC_THREADS) prednet_step_kernel(const StepK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Hp = p.Hp, L = p.L;
+  float* h = reinterpret_cast<float*>(smem);
+  float* c = h + L * Hp;
+  float* gi = c + L * Hp;
+  float* gh = gi + 4 * Hp;
+  float* x = gh + 4 * Hp;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int NG = p.cell == RNNT_CELL_LSTM ? 4 : (p.cell == RNNT_CELL_GRU ? 3 : 1);
+  for (int i = tid; i < L * Hp; i += DEC_THREADS) {
+    const int l = i / Hp, j = i % Hp;
+    h[i] = p.h_in ? p.h_in[((long)l * p.B + b) * Hp + j] : 0.f;
+    c[i] = (p.c_in && p.cell == RNNT_CELL_LSTM) ? p.c_in[((long)l * p.B + b) * Hp + j] : 0.f;
+  }
+  const long long tok = p.tokens[b];
+  for (int i = tid; i < Hp; i += DEC_THREADS) x[i] = p.emb[tok * Hp + i];
+  __syncthreads();
+  for (int l = 0; l < L; ++l) {
+    matvec(p.w_ih[l], Hp, NG * Hp, Hp, x, gi, p.b_ih[l]);
+    matvec(p.w_hh[l], Hp, NG * Hp, Hp, h + l * Hp, gh, p.b_hh[l]);
+    __syncthreads();
+    for (int j = tid; j < Hp; j += DEC_THREADS) {
+      float hv;
+      if (p.cell == RNNT_CELL_LSTM) {
+        const float ig = sigmoidf_(gi[j] + gh[j]), fg = sigmoidf_(gi[Hp + j] + gh[Hp + j]);
+        const float gg = tanhf(gi[2 * Hp + j] + gh[2 * Hp + j]), og = sigmoidf_(gi[3 * Hp + j] + gh[3 * Hp + j]);
+        const float cv = fg * c[l * Hp + j] + ig * gg;
+        c[l * Hp + j] = cv;
+        hv = og * tanhf(cv);
+      } else if (p.cell == RNNT_CELL_GRU) {
+        const float rg = sigmoidf_(gi[j] + gh[j]), zg = sigmoidf_(gi[Hp + j] + gh[Hp + j]);
+        const float ng = tanhf(gi[2 * Hp + j] + rg * gh[2 * Hp + j]);
+        hv = (1.f - zg) * ng + zg * h[l * Hp + j];
+      } else {
+        const float pre = gi[j] + gh[j];
+        hv = p.cell == RNNT_CELL_RNN_RELU ? fmaxf(pre, 0.f) : tanhf(pre);
+      }
+      h[l * Hp + j] = hv;
+      x[j] = hv;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < L * Hp; i += DEC_THREADS) {
+    const int l = i / Hp, j = i % Hp;
+    p.h_out[((long)l * p.B + b) * Hp + j] = h[i];
+    if (p.c_out && p.cell == RNNT_CELL_LSTM) p.c_out[((long)l * p.B + b) * Hp + j] = c[i];
+  }
+}
+
 }  // namespace
 }  // namespace rnnt
 
@@ -211,6 +278,30 @@ extern "C" int rnnt_hip_greedy_decode(const rnnt_decode_desc* d, void* stream) {
     RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)greedy_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope prof(RNNT_K_MISC, 4.0 * (double)d->T * d->B * d->V, (hipStream_t)stream);
   hipLaunchKernelGGL(greedy_decode_kernel, dim3(d->B), dim3(DEC_THREADS), lds, (hipStream_t)stream, k);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+extern "C" int rnnt_hip_prednet_step(const rnnt_prednet_step_desc* d, void* stream) {
+  RNNT_CHECK_ARG(d != nullptr, "prednet_step: null descriptor");
+  RNNT_CHECK_ARG(d->B >= 1 && d->Hp >= 4 && d->Hp % 4 == 0, "prednet_step: bad dims (hidden size must be a multiple of 4)");
+  RNNT_CHECK_ARG(d->L >= 1 && d->L <= DEC_MAX_LAYERS, "prednet_step: 1..%d layers", DEC_MAX_LAYERS);
+  RNNT_CHECK_ARG(d->cell >= RNNT_CELL_LSTM && d->cell <= RNNT_CELL_RNN_RELU, "prednet_step: unknown cell type");
+  RNNT_CHECK_ARG(d->tokens && d->emb && d->h_out && (d->c_out || d->cell != RNNT_CELL_LSTM), "prednet_step: null pointer");
+  StepK k;
+  k.B = d->B; k.Hp = d->Hp; k.L = d->L; k.cell = d->cell;
+  k.tokens = (const long long*)d->tokens; k.emb = d->emb;
+  for (int l = 0; l < d->L; ++l) {
+    RNNT_CHECK_ARG(d->w_ih[l] && d->w_hh[l] && d->b_ih[l] && d->b_hh[l], "prednet_step: null weight (layer %d)", l);
+    k.w_ih[l] = d->w_ih[l]; k.w_hh[l] = d->w_hh[l]; k.b_ih[l] = d->b_ih[l]; k.b_hh[l] = d->b_hh[l];
+  }
+  k.h_in = d->h_in; k.c_in = d->c_in; k.h_out = d->h_out; k.c_out = d->c_out;
+  const size_t lds = ((size_t)2 * d->L * d->Hp + 9 * d->Hp) * 4;
+  RNNT_CHECK_ARG(lds <= 160 * 1024, "prednet_step: state needs %zu B of LDS (> 160 KiB)", lds);
+  if (lds > 64 * 1024)
+    RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)prednet_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ProfScope prof(RNNT_K_MISC, 8.0 * (double)d->L * d->B * d->Hp, (hipStream_t)stream);
+  hipLaunchKernelGGL(prednet_step_kernel, dim3(d->B), dim3(DEC_THREADS), lds, (hipStream_t)stream, k);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }

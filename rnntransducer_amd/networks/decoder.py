@@ -2,15 +2,15 @@
 
 Mirrors networks/decoder.py:57-80 (ctor) and :82-126 (forward, packed branch :102-120,124) of the reference:
 Embedding(V, H, padding_idx=blank) -> LSTM -> Linear(H -> O); returns (outputs, hidden_states).
-The single-step branch (`prev_hidden_state`, decoder.py:121-123) belongs to greedy/beam decoding, which is
-out of scope for the training hot path: it raises NotImplementedError here.
+The step branch (`input_lengths=None`, carried `prev_hidden_state`, decoder.py:121-123) that the reference's search loops call
+is one launch of `rnnt_hip_prednet_step` per token column (inference only: no autograd through it).
 """
 from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 
-from ..ops import EmbeddingFn
+from ..ops import EmbeddingFn, LinearFn, prednet_step
 from .encoder import HipLinear, lengths_to_device
 from .rnn import RNN_CELLS
 
@@ -41,9 +41,21 @@ class TextPredNet(nn.Module):
         emb = self.embedding(inputs.transpose(0, 1).contiguous())  # (U1,B,H)
         return self.out_proj(self.rnn(emb, lens_dev))
 
-    def forward(self, inputs: torch.Tensor, input_lengths=None,
-                prev_hidden_state: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, None]:
-        if prev_hidden_state is not None or input_lengths is None:
-            raise NotImplementedError("single-step decoding branch (decoder.py:121-123) is outside the training hot path")
-        lens = lengths_to_device(input_lengths, inputs.device)
-        return self.forward_time_major(inputs, lens).transpose(0, 1).contiguous(), None
+    def forward(self, inputs: torch.Tensor, input_lengths=None, prev_hidden_state=None):
+        """Training branch (input_lengths given): (B,U1) tokens -> ((B,U1,O), None).
+        Step branch (input_lengths None, decoder.py:121-123): (B,S) tokens fed one column at a time from `prev_hidden_state`
+        (None = zeros; LSTM: a (h, c) tuple of (L,B,H) tensors, GRU / RNN: h) -> ((B,S,O), new hidden state in torch's format)."""
+        if input_lengths is not None:
+            if prev_hidden_state is not None:
+                raise ValueError("prev_hidden_state goes with the step branch (input_lengths=None), as in decoder.py:102-123")
+            lens = lengths_to_device(input_lengths, inputs.device)
+            return self.forward_time_major(inputs, lens).transpose(0, 1).contiguous(), None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("the step branch is inference-only: call it under torch.no_grad()")
+        lstm = self.rnn.CELL == 0
+        h, c = (prev_hidden_state if lstm else (prev_hidden_state, None)) if prev_hidden_state is not None else (None, None)
+        outs = []
+        for s_ in range(inputs.size(1)):
+            h, c = prednet_step(inputs[:, s_], self.embedding.weight, self.rnn.flat_weights(), self.rnn.CELL, h, c)
+            outs.append(LinearFn.apply(h[-1], self.out_proj.weight, self.out_proj.bias))
+        return torch.stack(outs, dim=1), ((h, c) if lstm else h)

@@ -30,9 +30,14 @@ class JointNet(nn.Module):
         self.fc = HipLinear(self.enc_out + self.dec_out, num_classes)
 
     def joint(self, encoder_outputs: torch.Tensor, decoder_outputs: torch.Tensor) -> torch.Tensor:
-        """(B,T,O_e), (B,U+1,O_d) -> logits (B,T,U+1,V) (materialising; transducer.py:54-69)."""
+        """(B,T,O_e), (B,U+1,O_d) -> logits (B,T,U+1,V) (materialising; transducer.py:54-69).  1-D inputs (one encoder frame,
+        one prediction-net output: the search loops' call at transducer.py:125,309) -> logits (V,)."""
+        if encoder_outputs.dim() == 1 and decoder_outputs.dim() == 1:
+            from ..ops import LinearFn
+            z = torch.cat((encoder_outputs, decoder_outputs)).unsqueeze(0)
+            return LinearFn.apply(torch.nn.functional.gelu(z, approximate="tanh"), self.fc.weight, self.fc.bias).squeeze(0)
         if encoder_outputs.dim() != 3 or decoder_outputs.dim() != 3:
-            raise NotImplementedError("1-D single-step joint (decoding, transducer.py:125,309) is out of scope")
+            raise ValueError("joint takes (B,T,O) with (B,U+1,O), or two 1-D vectors")
         return JointLogitsFn.apply(encoder_outputs.transpose(0, 1).contiguous(),
                                    decoder_outputs.transpose(0, 1).contiguous(), self.fc.weight, self.fc.bias)
 

@@ -429,3 +429,29 @@ def greedy_decode(enc_tm: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor, 
     d.tokens, d.ntok = _addr(tokens), _addr(ntok)
     check(_lib.lib().rnnt_hip_greedy_decode(C.byref(d), _stream()), "rnnt_hip_greedy_decode")
     return tokens, ntok
+
+
+def prednet_step(tokens: torch.Tensor, emb_w: torch.Tensor, rnn_weights, cell: int, h_in=None, c_in=None):
+    """One prediction-net step for a batch with carried state (decoder.py:121-123).  tokens (B,) int64; h_in / c_in (L,B,H)
+    or None (zeros) -> (h_out, c_out) with c_out None unless LSTM; the layer output is h_out[-1]."""
+    _need_gpu(tokens, emb_w)
+    L = len(rnn_weights) // 4
+    B, H = tokens.numel(), emb_w.shape[1]
+    if L > _lib.DECODE_MAX_LAYERS:
+        raise ValueError(f"at most {_lib.DECODE_MAX_LAYERS} prediction-net layers")
+    tokens = tokens.reshape(-1).to(torch.int64).contiguous()
+    h_out = torch.empty(L, B, H, device=emb_w.device, dtype=torch.float32)
+    c_out = torch.empty_like(h_out) if cell == _lib.CELL_LSTM else None
+    d = _lib.PrednetStepDesc()
+    d.B, d.Hp, d.L, d.cell = B, H, L, cell
+    d.tokens, d.emb = _addr(tokens), _addr(emb_w)
+    keep = []
+    for l in range(L):
+        w = [_f32c(t, "prediction-net weight") for t in rnn_weights[4 * l:4 * l + 4]]
+        keep.append(w)
+        d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (_addr(t) for t in w)
+    h_in = None if h_in is None else _f32c(h_in, "h_in")
+    c_in = None if c_in is None else _f32c(c_in, "c_in")
+    d.h_in, d.c_in, d.h_out, d.c_out = _addr(h_in), _addr(c_in), _addr(h_out), _addr(c_out)
+    check(_lib.lib().rnnt_hip_prednet_step(C.byref(d), _stream()), "rnnt_hip_prednet_step")
+    return h_out, c_out

@@ -153,3 +153,34 @@ def test_synthetic_pipeline_example_learns():
     spec.loader.exec_module(mod)
     first, last, ep = mod.main(["--steps", "60", "--batch", "4", "--seconds", "1.2"])
     assert last < 0.5 * first and 0.0 <= ep["val_ter"].item() <= 1.5
+
+
+@pytest.mark.parametrize("cell,layers", [("lstm", 2), ("gru", 1), ("rnn", 2)])
+def test_prednet_step_branch_and_1d_joint_match_oracle(cell, layers):
+    """The step-wise surface the reference's search loops use (decoder.py:121-123 with carried state, transducer.py:64-69 on
+    1-D vectors) against torch.nn stepping on the CPU: a (B,3) token block from None, then one more column from the state."""
+    from oracle.rnnt_oracle import OracleJointNet
+    tn = dict(input_size=12, hidden_size=16, output_size=8, num_layers=1, dropout=0.0, bidirectional=True)
+    pn = dict(embedding_size=10, pad_token_id=0, hidden_size=32, output_size=8, num_layers=layers, rnn_type=cell, dropout=0.0)
+    torch.manual_seed(11)
+    ora = OracleJointNet(tn, pn, 10).eval()
+    net = _jointnet(tn, pn, 10)
+    net.load_state_dict(ora.state_dict())
+    net = net.cuda().eval()
+    toks = torch.tensor([[0, 3, 7], [0, 9, 1], [0, 2, 2], [0, 5, 4]])
+    nxt = torch.tensor([[6], [8], [1], [3]])
+    with torch.no_grad():
+        y_ref, st_ref = ora.decoder.rnn(ora.decoder.embedding(toks), None)
+        y2_ref, st2_ref = ora.decoder.rnn(ora.decoder.embedding(nxt), st_ref)
+        want1, want2 = ora.decoder.out_proj(y_ref), ora.decoder.out_proj(y2_ref)
+        got1, st = net.decoder(toks.cuda(), None, None)
+        got2, st2 = net.decoder(nxt.cuda(), prev_hidden_state=st)
+        assert (got1.cpu() - want1).abs().max() < 2e-5 and (got2.cpu() - want2).abs().max() < 2e-5
+        flat = lambda s: torch.cat([t.reshape(-1) for t in (s if isinstance(s, tuple) else (s,))])  # noqa: E731
+        assert (flat(tuple(t.cpu() for t in st2) if isinstance(st2, tuple) else st2.cpu()) - flat(st2_ref)).abs().max() < 2e-5
+        enc = torch.randn(8)
+        z = net.joint(enc.cuda(), got2[1, 0])
+        z_ref = ora.fc(torch.nn.functional.gelu(torch.cat((enc, want2[1, 0])), approximate="tanh"))
+        assert z.shape == (10,) and (z.cpu() - z_ref).abs().max() < 2e-5
+    with pytest.raises(RuntimeError):
+        net.decoder(nxt.cuda(), prev_hidden_state=st)  # inference-only: needs no_grad
