@@ -758,15 +758,18 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
 // Stash layouts (gates, cst, y) are those of v2, so lstm_bwd2_kernel consumes them unchanged.
 // dynamic LDS: part[4 waves][4 mb][64] f32x4 | abort
 // ================================================================================================
-template <int NKS, int CELL, int NWV = 4>
+// MB: 16-gate-column blocks per workgroup (the workgroup owns 4*MB hidden units); MB = 5 with 8 waves and K padded to 768 is
+// the H = 640 form: 32 workgroups per sync group, which fit one XCD (40 would not)
+template <int NKS, int CELL, int NWV = 4, int MB = 4>
 __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
-  constexpr int HS = 16;
+  constexpr int HS = 4 * MB;
+  static_assert(MB <= NWV, "one owner wave per gate-column block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
   constexpr int Kw = 32 * NKS;
   f32x4* part = reinterpret_cast<f32x4*>(smem);
-  int* abort_lds = reinterpret_cast<int*>(part + NWV * 4 * 64);
+  int* abort_lds = reinterpret_cast<int*>(part + NWV * MB * 64);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = D * p.G;
@@ -776,12 +779,12 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
 
-  bf16x8 wp[4][NKS][3];
+  bf16x8 wp[MB][NKS][3];
   {
     const float* W = p.w_hh[d];
     const int gate = lrow & 3;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
       const float* row = W + (long)(gate * H + j0 + 4 * mb + (lrow >> 2)) * H;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -812,9 +815,10 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
 
   // one cell per lane of waves 0..3: unit 4*wave + lq of this workgroup, batch row lrow of this group (with NWV = 8 the
   // upper four waves only contribute their K-slice of the product)
-  const bool ownw = wave < 4;
+  const bool ownw = wave < MB;
+  const int ownb = ownw ? wave : 0;
   const int brow = lrow;
-  const int ob = b0 + brow, oj = j0 + 4 * (wave & 3) + lq;
+  const int ob = b0 + brow, oj = j0 + 4 * ownb + lq;
   const bool inrow = ownw && brow < NBR;
   const bool valid = ownw && brow < p.Bg && ob < B;
   const int olen = valid ? p.lens[ob] : 0;
@@ -839,9 +843,9 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
     f32x4 xp = {0.f, 0.f, 0.f, 0.f};
     if (valid) xp = *reinterpret_cast<const f32x4*>(p.gates + g_off);
 
-    f32x4 acc[4];
+    f32x4 acc[MB];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     DBG_STAMP(0);
     if (s > 0) {
       if (!wait_flags(flags, p.NC, (unsigned)s, p.status, abort_lds)) return false;
@@ -858,7 +862,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) hp[pl] = __builtin_bit_cast(bf16x8, raw[ks][pl]);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+        for (int mb = 0; mb < MB; ++mb) {
           acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][2], hp[0], acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], hp[1], acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], hp[2], acc[mb], 0, 0, 0);
@@ -870,11 +874,11 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
       DBG_STAMP(2);
     }
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) part[(wave * 4 + mb) * 64 + lane] = acc[mb];
+    for (int mb = 0; mb < MB; ++mb) part[(wave * MB + mb) * 64 + lane] = acc[mb];
     __syncthreads();
-    f32x4 rec = part[(wave & 3) * 64 + lane];
+    f32x4 rec = part[ownb * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < NWV; ++w) rec += part[(w * 4 + (wave & 3)) * 64 + lane];
+    for (int w = 1; w < NWV; ++w) rec += part[(w * MB + ownb) * 64 + lane];
     const bool active = valid && t < olen;
     float hval = 0.f;
     f32x4 gact = {0.f, 0.f, 0.f, 0.f};
@@ -1115,14 +1119,16 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
 // Exchange buffer: partial[parity][group][producer][row][Kp] fp32.  Protocol, owners, cell math and stash as in v2.
 // dynamic LDS: red[256] f32x4 | dgs[16][DGS_LD] float | abort
 // ================================================================================================
-template <int NKS, int BQ, int CELL, int NWV = 4>
+// NOB: 16-unit output blocks per wave (Kp / 16 / NWV); MB: the workgroup owns 4*MB units = 16*MB gate columns
+template <int NOB, int BQ, int CELL, int NWV = 4, int MB = 4>
 __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
-  constexpr int HS = 16, UQ = 4;
+  constexpr int HS = 4 * MB, UQ = MB;
   constexpr int NT = 64 * NWV;
-  constexpr int NMB = 8 * NKS / NWV;    // 16-unit output blocks per wave: (Kp/16)/NWV with Kp = 128*NKS
+  constexpr int NMB = NOB;
+  constexpr int KSB = (16 * MB + 31) / 32;   // 32-deep k-steps over the own gate columns (zero padded)
   constexpr int NBR = 4 * BQ;           // exchange rows of the group
-  constexpr int DGS_LD = 68;            // floats per row of the dG image (64 + pad)
+  constexpr int DGS_LD = 32 * KSB + 4;   // floats per row of the dG image (+ pad)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
   f32x4* red = reinterpret_cast<f32x4*>(smem);
@@ -1137,22 +1143,22 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
 
-  bf16x8 wp[NMB][2][3];
+  bf16x8 wp[NMB][KSB][3];
   {
     const float* W = p.w_hh[d];
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
       const int u = 16 * (wave * NMB + mb) + lrow;  // output unit = column of W_hh
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KSB; ++ks) {
         const int c = 32 * ks + 8 * lq;             // own gate column 4*unit + gate; c is a multiple of 8
         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
         if (u < H) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (e < NGATE) {
-              lo[e] = W[(long)(e * H + j0 + (c >> 2)) * H + u];
-              hi[e] = W[(long)(e * H + j0 + (c >> 2) + 1) * H + u];
+              if ((c >> 2) < HS) lo[e] = W[(long)(e * H + j0 + (c >> 2)) * H + u];
+              if ((c >> 2) + 1 < HS) hi[e] = W[(long)(e * H + j0 + (c >> 2) + 1) * H + u];
             }
           }
         }
@@ -1171,7 +1177,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
 
   // cell owners (as v2): tid = ((obq*UQ + uq)*4 + i)*4 + j -> unit j0 + 4*uq + i, batch row 4*obq + j
   const bool owner = tid < BQ * HS * 4;
-  const int ojb = tid & 3, oi = (tid >> 2) & 3, ouq = (tid >> 4) % UQ, obq = (tid >> 4) / UQ;
+  const int ojb = tid & 3, oi = (tid >> 2) & 3, ouq = (tid >> 4) % UQ, obq = (tid >> 4) / UQ;  // valid for tid < BQ*HS*4
   const int brow = 4 * obq + ojb, ob = b0 + brow, oj = j0 + 4 * ouq + oi;
   const bool valid = owner && brow < p.Bg && ob < B;
   const int olen = valid ? p.lens[ob] : 0;
@@ -1183,12 +1189,14 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
   long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3);
   long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
   const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
-  // gather: item idx = tid + NT*i -> (unit quad idx&3, row (idx>>2) % NBR, producer idx / (4*NBR)); 4*NBR divides NT, so a
-  // thread always meets the same (row, quad) and sums over the producers it visits
-  const int grow = (tid >> 2) % NBR, guq = tid & 3;
-  const int gat_base = ((tid / (4 * NBR)) * NBR + grow) * Kp + j0 + 4 * guq;  // floats; + NT/(4*NBR) producers per i
-  const int gat_step = (NT / (4 * NBR)) * NBR * Kp;
-  const int nitems = p.NC * NBR * 4;
+  // gather: thread -> (row, unit quad) pair pr = tid % (NBR*UQ) and producer class q = tid / (NBR*UQ); it sums the partial
+  // slices of producers q, q + NQ, ... for that pair; owners then add the NQ class sums
+  constexpr int NPAIR = NBR * UQ, NQ = NT / NPAIR;
+  const int gq = tid / NPAIR, gpr = tid % NPAIR;
+  const int grow = gpr / UQ, guq = gpr % UQ;
+  const bool gact = gq < NQ;
+  const int gat_base = (gq * NBR + grow) * Kp + j0 + 4 * guq;  // floats; + NQ producers per visit
+  const int gat_step = NQ * NBR * Kp;
   // publish: lane -> row lrow, units 16*mbg + 4*lq .. +3
   const int pub_base = lrow < NBR ? ((wg * NBR + lrow) * Kp + 16 * wave * NMB + 4 * lq) * 4 : 0x7ffffff0;
   __syncthreads();
@@ -1222,12 +1230,12 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
       DBG_STAMP(1);  // flag wait
       const __amdgpu_buffer_rsrc_t src = px_rsrc[(s - 1) & 1];
       constexpr int NI = 4;
-      for (int i0 = 0; i0 * NT < nitems; i0 += NI) {
+      for (int w0 = 0; w0 < p.NC; w0 += NQ * NI) {
         i32x4 r[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          const bool ok = (i0 + i) * NT + tid < nitems;
-          r[i] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? (gat_base + (i0 + i) * gat_step) * 4 : 0x7ffffff0, 0, AUX_SC1);
+          const bool ok = gact && w0 + gq + NQ * i < p.NC;
+          r[i] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? (gat_base + (w0 / NQ + i) * gat_step) * 4 : 0x7ffffff0, 0, AUX_SC1);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) gsum += __builtin_bit_cast(f32x4, r[i]);
@@ -1239,9 +1247,8 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
     f32x4 dg4 = {0.f, 0.f, 0.f, 0.f}, dgh4 = {0.f, 0.f, 0.f, 0.f};
     if (owner) {
       float dh = dyv;
-      constexpr int NQ = NT / (4 * NBR);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) dh += red[q * 4 * NBR + brow * 4 + ouq][oi];
+      for (int q = 0; q < NQ; ++q) dh += red[q * NPAIR + brow * UQ + ouq][oi];
       if (active) {
         if constexpr (CELL == 0) {
           const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
@@ -1278,9 +1285,9 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
     __syncthreads();
     DBG_STAMP(3);  // LDS reduce + cell math
     {
-      bf16x8 gp[2][3];
+      bf16x8 gp[KSB][3];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KSB; ++ks) {
         const float* src = dgs + lrow * DGS_LD + 32 * ks + 8 * lq;
         split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), gp[ks]);
       }
@@ -1288,7 +1295,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
       for (int mb = 0; mb < NMB; ++mb) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KSB; ++ks) {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][2], gp[ks][0], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], gp[ks][1], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], gp[ks][2], acc, 0, 0, 0);
@@ -1500,6 +1507,7 @@ bool make_plan(int B, int H, int D, int cus, Plan* pl) {
 
 struct Plan2 {
   int HS, NC, G, Bg, BQ, Kp;
+  int MB = 4;  // register-form kernels: 16-gate-column blocks per workgroup (HS = 4*MB)
   size_t lds_fwd, lds_bwd;
 };
 
@@ -1539,13 +1547,16 @@ bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
   if (getenv("RNNT_LSTM_V1") || getenv("RNNT_LSTM_V2")) return false;
   if (H % 128 != 0 || B < 1 || D < 1 || D > 2) return false;
   const int nks = H / 128;
-  (void)bwd;
-  // H = 1024: 8 waves per workgroup, each with the operand registers of the H = 512 / 4-wave form (4 waves would need 384
-  // operand registers per lane: measured slower than v2)
-  // H = 768: 8 waves x 3 k-steps
+  // H = 768 / 1024: 8 waves x 3 / 4 k-steps (4 waves would need 288 / 384 operand registers per lane).
+  // H = 640: 20 units per workgroup (5 blocks), 8 waves, K padded to 768 -> 32 workgroups per sync group, which fit one XCD
+  //          (the 16-unit form has 40 and runs the write-through exchange: measured 4.9 / 7.1 us per step vs 3.2 / 2.9)
   if (!(nks >= 1 && nks <= 6) && nks != 8) return false;
-  if (nks >= 6 && getenv("RNNT_LSTM_NO_8WAVE")) return false;
-  const int NC = H / 16;
+  // (forward only: the backward of that form keeps 216 operand registers per lane and spills 66-80 under the 256-register cap
+  //  of two waves per SIMD -- c5 backward 66.0 vs 63.8 ms with the 16-unit / 4-wave form, forward 39.9 vs 44.3)
+  const bool h640 = nks == 5 && (!bwd || getenv("RNNT_LSTM_H640_BWD")) && !getenv("RNNT_LSTM_NO_H640_FORM");
+  if ((nks >= 6 || h640) && getenv("RNNT_LSTM_NO_8WAVE")) return false;
+  const int MB = h640 ? 5 : 4, HS = 4 * MB;
+  const int NC = H / HS;
   const int Gmax = cus / (D * NC);
   if (Gmax < 1) return false;
   int G = (int)ceil_div(B, 4);
@@ -1553,10 +1564,13 @@ bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
   const int Bg = (int)ceil_div(B, G);
   if (Bg > 16) return false;
   G = (int)ceil_div(B, Bg);
-  pl->HS = 16; pl->NC = NC; pl->G = G; pl->Bg = Bg; pl->BQ = Bg <= 4 ? 1 : (Bg <= 8 ? 2 : 4); pl->Kp = H;
-  const int nwv = nks >= 6 ? 8 : 4;
-  pl->lds_fwd = (size_t)nwv * 4 * 64 * 16 + 16;
-  pl->lds_bwd = (size_t)nwv * 64 * 16 + 16 * 68 * 4 + 16;
+  pl->HS = HS; pl->NC = NC; pl->G = G; pl->Bg = Bg; pl->BQ = Bg <= 4 ? 1 : (Bg <= 8 ? 2 : 4);
+  pl->Kp = h640 ? 768 : H;
+  pl->MB = MB;
+  const int nwv = (nks >= 6 || h640) ? 8 : 4;
+  const int ksb = (16 * MB + 31) / 32;
+  pl->lds_fwd = (size_t)nwv * MB * 64 * 16 + 16;
+  pl->lds_bwd = (size_t)nwv * 64 * 16 + 16 * (32 * ksb + 4) * 4 + 16;
   return true;
 }
 
@@ -1826,7 +1840,11 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
       else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1>, k, p2, p2.lds_fwd, s, "lstm_fwd3"); \
       else rc = launch_persistent2(lstm_fwd3_kernel<N, 2>, k, p2, p2.lds_fwd, s, "lstm_fwd3");                     \
     } while (0)
-    if (nks == 1) LAUNCH_V3(1);
+    if (p2.MB == 5) {  // H = 640: 5 blocks, 8 waves x 3 k-steps over K padded to 768
+      if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<3, 0, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+      else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<3, 1, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+      else rc = launch_persistent2(lstm_fwd3_kernel<3, 2, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+    } else if (nks == 1) LAUNCH_V3(1);
     else if (nks == 2) LAUNCH_V3(2);
     else if (nks == 3) LAUNCH_V3(3);
     else if (nks == 4) LAUNCH_V3(4);
@@ -1891,7 +1909,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     fused_db = true;
     db_rows = p2.G * 4 * p2.BQ;
     const int nks = p2.Kp / 128;
-#define LAUNCH_V4_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<N, BQ_, C>, k, p2, p2.lds_bwd, s, "lstm_bwd4")
+#define LAUNCH_V4_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<2 * (N), BQ_, C>, k, p2, p2.lds_bwd, s, "lstm_bwd4")
 #define LAUNCH_V4_B(N, C)                           \
     do {                                            \
       if (p2.BQ == 1) LAUNCH_V4_C(N, 1, C);         \
@@ -1904,7 +1922,20 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       else if (d->cell == RNNT_CELL_GRU) LAUNCH_V4_B(N, 1);        \
       else LAUNCH_V4_B(N, 2);                                      \
     } while (0)
-    if (nks == 1) LAUNCH_V4(1);
+    if (p2.MB == 5) {  // H = 640: own 80 gate columns (3 k-steps), 48 output blocks over 8 waves
+#define LAUNCH_V45_C(BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<6, BQ_, C, 8, 5>, k, p2, p2.lds_bwd, s, "lstm_bwd4", 512)
+#define LAUNCH_V45_B(C)                           \
+      do {                                        \
+        if (p2.BQ == 1) LAUNCH_V45_C(1, C);       \
+        else if (p2.BQ == 2) LAUNCH_V45_C(2, C);  \
+        else LAUNCH_V45_C(4, C);                  \
+      } while (0)
+      if (d->cell == RNNT_CELL_LSTM) LAUNCH_V45_B(0);
+      else if (d->cell == RNNT_CELL_GRU) LAUNCH_V45_B(1);
+      else LAUNCH_V45_B(2);
+#undef LAUNCH_V45_B
+#undef LAUNCH_V45_C
+    } else if (nks == 1) LAUNCH_V4(1);
     else if (nks == 2) LAUNCH_V4(2);
     else if (nks == 3) LAUNCH_V4(3);
     else if (nks == 4) LAUNCH_V4(4);
