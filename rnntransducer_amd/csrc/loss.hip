@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
     // A wave owns the frames tl = wave + 4*i (i < TT/4) of the tile and walks u in chunks of UC: dA of a frame (sum over
     // u) and dC of a label position (sum over the wave's frames) both accumulate in REGISTERS; the LDS adds that merge the
     // four waves' dC happen once per (u, wave) instead of once per (u, frame) -- 8x fewer, and they were the kernel's
-    // bottleneck at large V (c5: V = 2048).
+    // bottleneck at large V (c5: V = 2048) -- and in a fixed order.
     constexpr int NF = TT / 4, UC = 8;
     float a[NF], accA[NF];
     bool fok[NF];
@@ -373,10 +373,16 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
           accC[j] += g;
         }
       }
-      if (vok) {
+      // merge the four waves' sums in wave order: fixed order -> the step is bitwise reproducible (LDS float atomics were not);
+      // u0 / Ub are uniform over the workgroup, so every wave meets every barrier
 #pragma unroll
-        for (int j = 0; j < UC; ++j)
-          if (u0 + j <= Ub) atomicAdd(&dCs[(u0 + j) * 64 + lane], accC[j]);
+      for (int w = 0; w < 4; ++w) {
+        if (wave == w && vok) {
+#pragma unroll
+          for (int j = 0; j < UC; ++j)
+            if (u0 + j <= Ub) dCs[(u0 + j) * 64 + lane] += accC[j];
+        }
+        __syncthreads();
       }
     }
 #pragma unroll
