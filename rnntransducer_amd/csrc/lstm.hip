@@ -1844,6 +1844,11 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
       if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<3, 0, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
       else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<3, 1, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
       else rc = launch_persistent2(lstm_fwd3_kernel<3, 2, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+    } else if (nks == 4 && !getenv("RNNT_LSTM_NO_8WAVE")) {  // H = 512 forward: 8 waves x 2 k-steps (12.5 vs 13.1 ms per c2 step)
+      p2.lds_fwd = (size_t)8 * 4 * 64 * 16 + 16;
+      if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<2, 0, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+      else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<2, 1, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+      else rc = launch_persistent2(lstm_fwd3_kernel<2, 2, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
     } else if (nks == 1) LAUNCH_V3(1);
     else if (nks == 2) LAUNCH_V3(2);
     else if (nks == 3) LAUNCH_V3(3);
@@ -1935,7 +1940,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       else LAUNCH_V45_B(2);
 #undef LAUNCH_V45_B
 #undef LAUNCH_V45_C
-    } else if (nks == 1) LAUNCH_V4(1);
+    } else if (nks == 1) LAUNCH_V4(1);  // (H = 512 backward with 8 waves: 12.9 vs 11.9 ms per c2 step -> stays at 4)
     else if (nks == 2) LAUNCH_V4(2);
     else if (nks == 3) LAUNCH_V4(3);
     else if (nks == 4) LAUNCH_V4(4);
