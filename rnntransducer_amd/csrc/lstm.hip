@@ -1120,12 +1120,15 @@ __global__ void __launch_bounds__(256) lstm_bwd2_kernel(const LstmK p) {
 // dynamic LDS: red[256] f32x4 | dgs[16][DGS_LD] float | abort
 // ================================================================================================
 // NOB: 16-unit output blocks per wave (Kp / 16 / NWV); MB: the workgroup owns 4*MB units = 16*MB gate columns
-template <int NOB, int BQ, int CELL, int NWV = 4, int MB = 4>
+// NLB: of a wave's NOB output blocks, the last NLB keep their W_hh pieces in LDS (MFMA-operand order, one 16-byte fragment
+// per lane) instead of registers: the 8-wave forms run two waves per SIMD under a 256-register cap
+template <int NOB, int BQ, int CELL, int NWV = 4, int MB = 4, int NLB = 0>
 __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
   constexpr int HS = 4 * MB, UQ = MB;
   constexpr int NT = 64 * NWV;
   constexpr int NMB = NOB;
+  constexpr int NRB = NOB - NLB;          // output blocks whose W pieces stay in registers
   constexpr int KSB = (16 * MB + 31) / 32;   // 32-deep k-steps over the own gate columns (zero padded)
   constexpr int NBR = 4 * BQ;           // exchange rows of the group
   constexpr int DGS_LD = 32 * KSB + 4;   // floats per row of the dG image (+ pad)
@@ -1134,6 +1137,8 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
   f32x4* red = reinterpret_cast<f32x4*>(smem);
   float* dgs = reinterpret_cast<float*>(red + NT);
   int* abort_lds = reinterpret_cast<int*>(dgs + 16 * DGS_LD);
+  // [wave][NLB][KSB][3][64] 16-byte fragments, after a 16-byte aligned gap
+  u32x4* wl = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(abort_lds) + 16) + (long)(threadIdx.x >> 6) * NLB * KSB * 3 * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = D * p.G;
@@ -1143,7 +1148,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
 
-  bf16x8 wp[NMB][KSB][3];
+  bf16x8 wp[NRB > 0 ? NRB : 1][KSB][3];
   {
     const float* W = p.w_hh[d];
 #pragma unroll
@@ -1162,7 +1167,14 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
             }
           }
         }
-        split8(lo, hi, wp[mb][ks]);
+        if (mb < NRB) {
+          split8(lo, hi, wp[mb < NRB ? mb : 0][ks]);
+        } else {
+          bf16x8 tmp[3];
+          split8(lo, hi, tmp);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) wl[(((mb - NRB) * KSB + ks) * 3 + pl) * 64 + lane] = __builtin_bit_cast(u32x4, tmp[pl]);
+        }
       }
     }
     for (int i = tid; i < 16 * DGS_LD; i += NT) dgs[i] = 0.f;
@@ -1296,12 +1308,19 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][2], gp[ks][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], gp[ks][1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], gp[ks][2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], gp[ks][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], gp[ks][1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], gp[ks][0], acc, 0, 0, 0);
+          bf16x8 w0, w1, w2;
+          if (mb < NRB) {
+            w0 = wp[mb < NRB ? mb : 0][ks][0]; w1 = wp[mb < NRB ? mb : 0][ks][1]; w2 = wp[mb < NRB ? mb : 0][ks][2];
+          } else {
+            const u32x4* f = wl + ((mb - NRB) * KSB + ks) * 3 * 64 + lane;
+            w0 = __builtin_bit_cast(bf16x8, f[0]); w1 = __builtin_bit_cast(bf16x8, f[64]); w2 = __builtin_bit_cast(bf16x8, f[128]);
+          }
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, gp[ks][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, gp[ks][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, gp[ks][2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, gp[ks][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, gp[ks][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, gp[ks][0], acc, 0, 0, 0);
         }
         exchange_store<LOCAL>(__builtin_bit_cast(i32x4, acc), px_rsrc[s & 1], pub_base + 64 * mb);
       }
@@ -1551,9 +1570,10 @@ bool make_plan3(int B, int H, int D, int cus, bool bwd, Plan2* pl) {
   // H = 640: 20 units per workgroup (5 blocks), 8 waves, K padded to 768 -> 32 workgroups per sync group, which fit one XCD
   //          (the 16-unit form has 40 and runs the write-through exchange: measured 4.9 / 7.1 us per step vs 3.2 / 2.9)
   if (!(nks >= 1 && nks <= 6) && nks != 8) return false;
-  // (forward only: the backward of that form keeps 216 operand registers per lane and spills 66-80 under the 256-register cap
-  //  of two waves per SIMD -- c5 backward 66.0 vs 63.8 ms with the 16-unit / 4-wave form, forward 39.9 vs 44.3)
-  const bool h640 = nks == 5 && (!bwd || getenv("RNNT_LSTM_H640_BWD")) && !getenv("RNNT_LSTM_NO_H640_FORM");
+  // (its backward keeps one of the six output blocks' W_hh pieces in LDS: with all 216 operand registers per lane it spilled 66-80
+  //  and lost to the 16-unit / 4-wave form, 66.0 vs 63.8 ms per c5 step; with 180 it takes 45.5)
+  (void)bwd;
+  const bool h640 = nks == 5 && !getenv("RNNT_LSTM_NO_H640_FORM");
   if ((nks >= 6 || h640) && getenv("RNNT_LSTM_NO_8WAVE")) return false;
   const int MB = h640 ? 5 : 4, HS = 4 * MB;
   const int NC = H / HS;
@@ -1928,7 +1948,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       else LAUNCH_V4_B(N, 2);                                      \
     } while (0)
     if (p2.MB == 5) {  // H = 640: own 80 gate columns (3 k-steps), 48 output blocks over 8 waves
-#define LAUNCH_V45_C(BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<6, BQ_, C, 8, 5>, k, p2, p2.lds_bwd, s, "lstm_bwd4", 512)
+#define LAUNCH_V45_C(BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<6, BQ_, C, 8, 5, 1>, k, p2, p2.lds_bwd + 8 * 1 * 3 * 3 * 1024, s, "lstm_bwd4", 512)
 #define LAUNCH_V45_B(C)                           \
       do {                                        \
         if (p2.BQ == 1) LAUNCH_V45_C(1, C);       \
@@ -1946,7 +1966,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     else if (nks == 4) LAUNCH_V4(4);
     else if (nks == 5) LAUNCH_V4(5);
     else {  // H = 768 / 1024: 8 waves, 6 / 8 output blocks each
-#define LAUNCH_V48_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<N, BQ_, C, 8>, k, p2, p2.lds_bwd, s, "lstm_bwd4", 512)
+#define LAUNCH_V48_C(N, BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<N, BQ_, C, 8, 4, 2>, k, p2, p2.lds_bwd + 8 * 2 * 2 * 3 * 1024, s, "lstm_bwd4", 512)
 #define LAUNCH_V48_B(N, C)                           \
       do {                                           \
         if (p2.BQ == 1) LAUNCH_V48_C(N, 1, C);       \
