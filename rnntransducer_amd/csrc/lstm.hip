@@ -760,7 +760,9 @@ __global__ void __launch_bounds__(256) lstm_fwd2_kernel(const LstmK p) {
 // ================================================================================================
 // MB: 16-gate-column blocks per workgroup (the workgroup owns 4*MB hidden units); MB = 5 with 8 waves and K padded to 768 is
 // the H = 640 form: 32 workgroups per sync group, which fit one XCD (40 would not)
-template <int NKS, int CELL, int NWV = 4, int MB = 4>
+// NLB: the last NLB of the MB gate-column blocks keep their W_hh pieces in LDS instead of registers (8-wave forms: two waves
+// per SIMD share a 256-register cap)
+template <int NKS, int CELL, int NWV = 4, int MB = 4, int NLB = 0>
 __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
   constexpr int HS = 4 * MB;
@@ -770,6 +772,8 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
   constexpr int Kw = 32 * NKS;
   f32x4* part = reinterpret_cast<f32x4*>(smem);
   int* abort_lds = reinterpret_cast<int*>(part + NWV * MB * 64);
+  constexpr int NRB = MB - NLB;
+  u32x4* wl = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(abort_lds) + 16) + (long)(threadIdx.x >> 6) * NLB * NKS * 3 * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NG = D * p.G;
@@ -779,7 +783,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
 
-  bf16x8 wp[MB][NKS][3];
+  bf16x8 wp[NRB][NKS][3];
   {
     const float* W = p.w_hh[d];
     const int gate = lrow & 3;
@@ -797,7 +801,14 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
             if (k + 4 + e < H) hi[e] = row[k + 4 + e];
           }
         }
-        split8(lo, hi, wp[mb][ks]);
+        if (mb < NRB) {
+          split8(lo, hi, wp[mb < NRB ? mb : 0][ks]);
+        } else {
+          bf16x8 tmp[3];
+          split8(lo, hi, tmp);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) wl[(((mb - NRB) * NKS + ks) * 3 + pl) * 64 + lane] = __builtin_bit_cast(u32x4, tmp[pl]);
+        }
       }
     }
     if (tid == 0) *abort_lds = 0;
@@ -863,12 +874,19 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd3_kernel(const LstmK p) {
         for (int pl = 0; pl < 3; ++pl) hp[pl] = __builtin_bit_cast(bf16x8, raw[ks][pl]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][2], hp[0], acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], hp[1], acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], hp[2], acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][1], hp[0], acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], hp[1], acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[mb][ks][0], hp[0], acc[mb], 0, 0, 0);
+          bf16x8 w0, w1, w2;
+          if (mb < NRB) {
+            w0 = wp[mb < NRB ? mb : 0][ks][0]; w1 = wp[mb < NRB ? mb : 0][ks][1]; w2 = wp[mb < NRB ? mb : 0][ks][2];
+          } else {
+            const u32x4* f = wl + ((mb - NRB) * NKS + ks) * 3 * 64 + lane;
+            w0 = __builtin_bit_cast(bf16x8, f[0]); w1 = __builtin_bit_cast(bf16x8, f[64]); w2 = __builtin_bit_cast(bf16x8, f[128]);
+          }
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, hp[0], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, hp[1], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, hp[2], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, hp[0], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, hp[1], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, hp[0], acc[mb], 0, 0, 0);
         }
       }
       DBG_STAMP(2);
@@ -1861,9 +1879,10 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
       else rc = launch_persistent2(lstm_fwd3_kernel<N, 2>, k, p2, p2.lds_fwd, s, "lstm_fwd3");                     \
     } while (0)
     if (p2.MB == 5) {  // H = 640: 5 blocks, 8 waves x 3 k-steps over K padded to 768
-      if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<3, 0, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
-      else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<3, 1, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
-      else rc = launch_persistent2(lstm_fwd3_kernel<3, 2, 8, 5>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
+      const size_t lds5 = p2.lds_fwd + 8 * 1 * 3 * 3 * 1024;  // one of the five blocks' pieces in LDS
+      if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<3, 0, 8, 5, 1>, k, p2, lds5, s, "lstm_fwd3", 512);
+      else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<3, 1, 8, 5, 1>, k, p2, lds5, s, "lstm_fwd3", 512);
+      else rc = launch_persistent2(lstm_fwd3_kernel<3, 2, 8, 5, 1>, k, p2, lds5, s, "lstm_fwd3", 512);
     } else if (nks == 4 && !getenv("RNNT_LSTM_NO_8WAVE")) {  // H = 512 forward: 8 waves x 2 k-steps (12.5 vs 13.1 ms per c2 step)
       p2.lds_fwd = (size_t)8 * 4 * 64 * 16 + 16;
       if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<2, 0, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);
@@ -1876,10 +1895,11 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
     else if (nks == 5) LAUNCH_V3(5);
     else {  // H = 768 / 1024: 8 waves x 3 / 4 k-steps
 #define LAUNCH_V38(N)                                                                                                       \
-      do {                                                                                                                  \
-        if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<N, 0, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512); \
-        else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512); \
-        else rc = launch_persistent2(lstm_fwd3_kernel<N, 2, 8>, k, p2, p2.lds_fwd, s, "lstm_fwd3", 512);                     \
+      do {  /* one of the four blocks' pieces in LDS */                                                                     \
+        const size_t lds8 = p2.lds_fwd + 8 * 1 * (N) * 3 * 1024;                                                            \
+        if (d->cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd3_kernel<N, 0, 8, 4, 1>, k, p2, lds8, s, "lstm_fwd3", 512); \
+        else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1, 8, 4, 1>, k, p2, lds8, s, "lstm_fwd3", 512); \
+        else rc = launch_persistent2(lstm_fwd3_kernel<N, 2, 8, 4, 1>, k, p2, lds8, s, "lstm_fwd3", 512);                     \
       } while (0)
       if (nks == 6) LAUNCH_V38(3);
       else LAUNCH_V38(4);
