@@ -32,7 +32,9 @@ def _oracle(x, lens, ref, dy):
                                           (16, 6, 24, 1024, 1, True), (5, 4, 8, 1024, 2, False),
                                           (6, 7, 16, 384, 1, True), (9, 5, 16, 768, 1, True),
                                           # register form at the edges: one frame, one utterance, 3 ragged rows, 17 rows (two 9-row groups)
-                                          (1, 1, 8, 128, 1, True), (3, 2, 8, 256, 1, False), (17, 4, 8, 128, 2, True)])
+                                          (1, 1, 8, 128, 1, True), (3, 2, 8, 256, 1, False), (17, 4, 8, 128, 2, True),
+                                          # 8-wave forms with 16-row groups
+                                          (32, 4, 8, 1024, 1, True), (64, 3, 8, 640, 1, True)])
 def test_lstm_stack_fwd_bwd(B, T, I, H, L, bi):
     from rnntransducer_amd.networks.rnn import HipLSTM
     from rnntransducer_amd.ops import lstm_check, lstm_workspace
