@@ -153,6 +153,7 @@ __device__ __forceinline__ double shfl_down1(double x, int lane) {
   return lane == 63 ? NEG_INF : y;
 }
 
+constexpr int PF = 8;  // rows of blk/emit in flight per lane (register ring)
 template <int K>
 __global__ void __launch_bounds__(64) alphabeta_kernel(const float* __restrict__ blk, const float* __restrict__ emit,
                                                        const int* __restrict__ t_lens, const int* __restrict__ u_lens,
@@ -170,43 +171,51 @@ __global__ void __launch_bounds__(64) alphabeta_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < K; ++k) down[k] = NEG_INF;
     double eout = NEG_INF;  // alpha[t][uhi] + emit[t][uhi] of this lane's last cell at its current row
-    float pb[K], pe[K];
-    // prefetch row t = 0 - lane (only lane 0 valid at n = 0)
+    // The sweep is a chain of ~T dependent steps; a row's blk/emit values are fetched PF steps ahead into a register ring
+    // (one step ahead left every step waiting out a global-load latency: 535 ns per step at c2)
+    float pb[PF][K], pe[PF][K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int u = ulo + k, t = 0 - lane;
-      const bool ok = (t >= 0 && t < Tb && u <= Ub);
-      pb[k] = ok ? blk[rowbase + (long)u * T + t] : 0.f;
-      pe[k] = ok ? emit[rowbase + (long)u * T + t] : 0.f;
-    }
-    for (int n = 0; n < nsteps; ++n) {
-      const int t = n - lane;
-      const double carry = shfl_up1(eout, lane);
-      float cb[K], ce[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) { cb[k] = pb[k]; ce[k] = pe[k]; }
-      // prefetch next row
+    for (int j = 0; j < PF; ++j)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int u = ulo + k, tn = t + 1;
-        const bool ok = (tn >= 0 && tn < Tb && u <= Ub);
-        pb[k] = ok ? blk[rowbase + (long)u * T + tn] : 0.f;
-        pe[k] = ok ? emit[rowbase + (long)u * T + tn] : 0.f;
+        const int u = ulo + k, t = j - lane;
+        const bool ok = (t >= 0 && t < Tb && u <= Ub);
+        pb[j][k] = ok ? blk[rowbase + (long)u * T + t] : 0.f;
+        pe[j][k] = ok ? emit[rowbase + (long)u * T + t] : 0.f;
       }
-      if (t >= 0 && t < Tb) {
-        double left = carry;
+    for (int n0 = 0; n0 < nsteps; n0 += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int n = n0 + j;
+        if (n >= nsteps) break;
+        const int t = n - lane;
+        const double carry = shfl_up1(eout, lane);
+        float cb[K], ce[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { cb[k] = pb[j][k]; ce[k] = pe[j][k]; }
+        // refill this ring slot with the row of step n + PF
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const int u = ulo + k;
-          if (u <= Ub) {
-            const double a = (t == 0 && u == 0) ? 0.0 : logaddexp_d(down[k], left);
-            alpha[rowbase + (long)u * T + t] = a;
-            down[k] = a + (double)cb[k];
-            left = (u < Ub) ? a + (double)ce[k] : NEG_INF;
-            if (t == Tb - 1 && u == Ub) ll[b] = down[k];
-          }
+          const int u = ulo + k, tn = t + PF;
+          const bool ok = (tn >= 0 && tn < Tb && u <= Ub);
+          pb[j][k] = ok ? blk[rowbase + (long)u * T + tn] : 0.f;
+          pe[j][k] = ok ? emit[rowbase + (long)u * T + tn] : 0.f;
         }
-        eout = left;
+        if (t >= 0 && t < Tb) {
+          double left = carry;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const int u = ulo + k;
+            if (u <= Ub) {
+              const double a = (t == 0 && u == 0) ? 0.0 : logaddexp_d(down[k], left);
+              alpha[rowbase + (long)u * T + t] = a;
+              down[k] = a + (double)cb[k];
+              left = (u < Ub) ? a + (double)ce[k] : NEG_INF;
+              if (t == Tb - 1 && u == Ub) ll[b] = down[k];
+            }
+          }
+          eout = left;
+        }
       }
     }
   } else {
@@ -214,49 +223,56 @@ __global__ void __launch_bounds__(64) alphabeta_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < K; ++k) down[k] = NEG_INF;
     double bout = NEG_INF;  // beta[t][ulo] of this lane's first cell at its current row
-    float pb[K], pe[K];
     // lane l at step n handles t = Tb-1 - (n - (lastlane - l)); lanes > lastlane own no valid cell
+    float pb[PF][K], pe[PF][K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int u = ulo + k, t = Tb - 1 + (lastlane - lane);
-      const bool ok = (t >= 0 && t < Tb && u <= Ub);
-      pb[k] = ok ? blk[rowbase + (long)u * T + t] : 0.f;
-      pe[k] = ok ? emit[rowbase + (long)u * T + t] : 0.f;
-    }
-    for (int n = 0; n < nsteps; ++n) {
-      const int t = Tb - 1 - (n - (lastlane - lane));
-      const double carry = shfl_down1(bout, lane);  // beta[t][(lane+1)*K]
-      float cb[K], ce[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) { cb[k] = pb[k]; ce[k] = pe[k]; }
+    for (int j = 0; j < PF; ++j)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int u = ulo + k, tn = t - 1;
-        const bool ok = (tn >= 0 && tn < Tb && u <= Ub);
-        pb[k] = ok ? blk[rowbase + (long)u * T + tn] : 0.f;
-        pe[k] = ok ? emit[rowbase + (long)u * T + tn] : 0.f;
+        const int u = ulo + k, t = Tb - 1 - (j - (lastlane - lane));
+        const bool ok = (t >= 0 && t < Tb && u <= Ub);
+        pb[j][k] = ok ? blk[rowbase + (long)u * T + t] : 0.f;
+        pe[j][k] = ok ? emit[rowbase + (long)u * T + t] : 0.f;
       }
-      if (t >= 0 && t < Tb && lane <= lastlane) {
-        double right = carry;  // beta[t][u+1]
+    for (int n0 = 0; n0 < nsteps; n0 += PF) {
 #pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
-          const int u = ulo + k;
-          if (u <= Ub) {
-            double v;
-            if (t == Tb - 1 && u == Ub) {
-              v = (double)cb[k];
-            } else {
-              const double ne = down[k] == NEG_INF ? NEG_INF : down[k] + (double)cb[k];
-              const double em = (u < Ub && right != NEG_INF) ? right + (double)ce[k] : NEG_INF;
-              v = logaddexp_d(ne, em);
-            }
-            beta[rowbase + (long)u * T + t] = v;
-            down[k] = v;
-            right = v;
-            if (t == 0 && u == 0) ll[gridDim.x + b] = v;
-          }
+      for (int j = 0; j < PF; ++j) {
+        const int n = n0 + j;
+        if (n >= nsteps) break;
+        const int t = Tb - 1 - (n - (lastlane - lane));
+        const double carry = shfl_down1(bout, lane);  // beta[t][(lane+1)*K]
+        float cb[K], ce[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { cb[k] = pb[j][k]; ce[k] = pe[j][k]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int u = ulo + k, tn = t - PF;
+          const bool ok = (tn >= 0 && tn < Tb && u <= Ub);
+          pb[j][k] = ok ? blk[rowbase + (long)u * T + tn] : 0.f;
+          pe[j][k] = ok ? emit[rowbase + (long)u * T + tn] : 0.f;
         }
-        bout = right;
+        if (t >= 0 && t < Tb && lane <= lastlane) {
+          double right = carry;  // beta[t][u+1]
+#pragma unroll
+          for (int k = K - 1; k >= 0; --k) {
+            const int u = ulo + k;
+            if (u <= Ub) {
+              double v;
+              if (t == Tb - 1 && u == Ub) {
+                v = (double)cb[k];
+              } else {
+                const double ne = down[k] == NEG_INF ? NEG_INF : down[k] + (double)cb[k];
+                const double em = (u < Ub && right != NEG_INF) ? right + (double)ce[k] : NEG_INF;
+                v = logaddexp_d(ne, em);
+              }
+              beta[rowbase + (long)u * T + t] = v;
+              down[k] = v;
+              right = v;
+              if (t == 0 && u == 0) ll[gridDim.x + b] = v;
+            }
+          }
+          bout = right;
+        }
       }
     }
   }
