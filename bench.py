@@ -61,35 +61,103 @@ def build_model(cfg, dropout, total_steps):
     return RNNTransducer(pn, tn, dict(num_classes=V), args), tn, pn
 
 
-def cpu_baseline(model, tn, pn, V, batch, sample_b, threads):
-    """The oracle's full training step on `sample_b` utterances of the same workload, on host cores."""
-    from oracle.rnnt_oracle import OracleJointNet, training_loss
+def host_cpu_info():
+    """(usable cores, model string): cores = CPUs this process may run on (affinity mask, further clamped by a cgroup
+    cpu.max quota if one is set) — what torch.set_num_threads() gets; the model string is /proc/cpuinfo's."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cores, model
+
+
+def _oracle_for(model, tn, pn, V, double):
+    from oracle.rnnt_oracle import OracleJointNet
+    oracle = OracleJointNet(dict(tn, dropout=0.0), dict(pn, pad_token_id=0, dropout=0.0), V)
+    if double:
+        oracle = oracle.double()
+    oracle.load_state_dict({k[len("jointnet."):]: (v.detach().cpu().double() if double else v.detach().cpu())
+                            for k, v in model.state_dict().items()})
+    return oracle
+
+
+def cpu_baseline(model, tn, pn, V, batch, sample_b, threads, timed_steps=3):
+    """BASELINE.md §3 protocol: the oracle's full training step (fwd + RNN-T loss + bwd + AdamW, fp32, the MATERIALISING
+    joint of networks/transducer.py:58-69) on `sample_b` utterances of the same workload on the host cores:
+    1 warm-up step + `timed_steps` timed steps, median reported."""
+    from oracle.rnnt_oracle import training_loss
     torch.set_num_threads(threads)
     os.environ["OMP_NUM_THREADS"] = str(threads)
-    oracle = OracleJointNet(dict(tn, dropout=0.0), dict(pn, pad_token_id=0, dropout=0.0), V)
-    oracle.load_state_dict({k[len("jointnet."):]: v.detach().cpu() for k, v in model.state_dict().items()})
+    oracle = _oracle_for(model, tn, pn, V, double=False)
     opt = torch.optim.AdamW(oracle.parameters(), lr=1e-3, weight_decay=1e-4)
     sub = tuple((x[:sample_b].cpu() if isinstance(x, torch.Tensor) else x[:sample_b]) for x in batch)
-    t0 = time.perf_counter()
-    loss = training_loss(oracle, sub)
-    loss.backward()
-    grads = {k: p.grad.detach().clone() for k, p in oracle.named_parameters() if k in GRAD_PROBES}
-    opt.step()
-    dt = time.perf_counter() - t0
-    return sample_b / dt, float(loss.detach()), dt, grads
+    times = []
+    for _ in range(1 + timed_steps):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = training_loss(oracle, sub)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    return sample_b / med, med, times
+
+
+def parity_vs_float64_oracle(model, tn, pn, V, batch, nb, threads):
+    """Loss + the three probe gradients (SURVEY §8d "Loss delta") of the HIP path on the CURRENT weights, dropout off,
+    against the float64 oracle on the first `nb` utterances of the bench batch."""
+    from oracle.rnnt_oracle import training_loss
+    torch.set_num_threads(threads)
+    was_training = model.training
+    model.eval()
+    sub = tuple((x[:nb] if isinstance(x, torch.Tensor) else x[:nb]) for x in batch)
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    hip_l = model.jointnet.loss(sub[0], sub[2], sub[3], sub[5], sub[6], model.blank_token_id).mean()
+    hip_l.backward()
+    hip_loss = float(hip_l.detach())
+    hip_grads = {k: p.grad.detach().double().cpu().clone() for k, p in model.jointnet.named_parameters() if k in GRAD_PROBES}
+    model.train(was_training)
+    oracle = _oracle_for(model, tn, pn, V, double=True)
+    cpu_sub = tuple((x.cpu() if isinstance(x, torch.Tensor) else x) for x in sub)
+    ref = training_loss(oracle, (cpu_sub[0].double(),) + cpu_sub[1:])
+    ref.backward()
+    ref_grads = {k: p.grad for k, p in oracle.named_parameters() if k in GRAD_PROBES}
+    devs = {k: {"max_abs_dev": float((hip_grads[k] - ref_grads[k]).abs().max()), "ref_max_abs": float(ref_grads[k].abs().max())}
+            for k in GRAD_PROBES}
+    for v in devs.values():
+        v["rel_to_max"] = v["max_abs_dev"] / max(v["ref_max_abs"], 1e-30)
+    return abs(hip_loss - float(ref)) / abs(float(ref)), devs
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=list(CONFIGS))
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--ragged", action="store_true", help="KsponSpeech-shaped ragged lengths (SURVEY §8d c4 variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4, help="utterances in the CPU-baseline sample")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every core this process may use (measured)")
+    ap.add_argument("--parity-sample", type=int, default=2, help="utterances in the float64 parity leg")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -234,29 +302,32 @@ def main():
                      "reference_logits_bytes": int(B) * T * (U + 1) * V * 4,
                      "stash_note": "peak is dominated by the LSTM stash (activated gates, 16*H bytes per frame per direction per layer)"}
 
+    parity_ok = True
     if world == 1 and not a.no_cpu_baseline:
-        # loss parity on the sample: HIP with dropout off vs the oracle (same weights, same utterances)
+        cores, cpu_model = host_cpu_info()
+        threads = a.cpu_threads or cores
+        # (1) parity: HIP (dropout off, CURRENT weights — they moved during the timed steps) vs the FLOAT64 oracle
+        npar = min(a.parity_sample, B)
+        out["loss_rel_delta"], out["grad_max_abs_dev"] = parity_vs_float64_oracle(model, tn, pn, V, batch, npar, threads)
+        out["parity"] = {"oracle": f"float64 CPU oracle, first {npar} utterances of the bench batch, dropout off",
+                         "loss_rel_tol": 1e-4, "grad_tol": "max_abs_dev <= 2e-4 * max(ref_max_abs, 1e-3) (the bound tests/test_gpu_model.py uses)"}
+        parity_ok = out["loss_rel_delta"] <= 1e-4 and all(v["max_abs_dev"] <= 2e-4 * max(v["ref_max_abs"], 1e-3) for v in out["grad_max_abs_dev"].values())
+        out["parity"]["ok"] = parity_ok
+        # (2) reported CPU baseline: fp32 oracle, 1 warm-up + 3 timed full train steps, median
         nb = min(a.cpu_sample, B)
-        model.eval()  # dropout off; weights moved during the timed steps: compare on the CURRENT weights
-        sub = tuple((x[:nb] if isinstance(x, torch.Tensor) else x[:nb]) for x in batch)
-        opt.zero_grad()
-        hip_l = model.jointnet.loss(sub[0], sub[2], sub[3], sub[5], sub[6], model.blank_token_id).mean()
-        hip_l.backward()
-        hip_loss = float(hip_l.detach())
-        hip_grads = {k: p.grad.detach().cpu().clone() for k, p in model.jointnet.named_parameters() if k in GRAD_PROBES}
-        model.train()
-        v, oracle_loss, secs, ref_grads = cpu_baseline(model, tn, pn, V, batch, nb, a.cpu_threads)
-        out["grad_max_abs_dev"] = {k: {"max_abs_dev": float((hip_grads[k] - ref_grads[k]).abs().max()),
-                                       "ref_max_abs": float(ref_grads[k].abs().max())} for k in GRAD_PROBES}
-        out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": a.cpu_threads, "kind": "port",
-                               "sample": f"1 full train step (fwd+RNN-T loss+bwd+AdamW) of the oracle on {nb} utterances of the same "
-                                         f"workload, {secs:.1f} s, torch.set_num_threads({a.cpu_threads})"}
-        out["loss_rel_delta"] = abs(hip_loss - oracle_loss) / abs(oracle_loss)
+        v, med, times = cpu_baseline(model, tn, pn, V, batch, nb, threads)
+        out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": threads, "kind": "port",
+                               "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
+                               "sample": f"full train steps (fwd + RNN-T loss + bwd + AdamW, fp32, materialising joint) of the oracle on "
+                                         f"{nb} utterances of the same workload: 1 warm-up ({times[0]:.1f} s) + {len(times) - 1} timed, median "
+                                         f"{med:.1f} s/step, torch.set_num_threads({threads})"}
         out["speedup_vs_cpu_baseline"] = round(out["value"] / v, 1)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit("bench.py: parity leg outside tolerance (see loss_rel_delta / grad_max_abs_dev in the line above)")
 
 
 if __name__ == "__main__":

@@ -10,7 +10,9 @@
  *   - plain `extern "C"`, raw device pointers + explicit dims, `void* stream` is a hipStream_t;
  *   - return 0 on success, <0 on error; rnnt_hip_last_error() gives a thread-local message;
  *   - the CALLER owns all memory incl. workspaces (sizes from *_workspace_bytes); the library never
- *     allocates or frees device memory, never synchronises the device, keeps no global mutable state;
+ *     allocates or frees device memory, never synchronises the device (the two *_check / *_debug_read
+ *     diagnostics aside) and keeps no global mutable state other than the opt-in profiler below
+ *     (off by default: event lists + a mutex behind rnnt_hip_prof_enable) and the thread-local error string;
  *   - all float tensors are fp32, all lengths/labels int32, token ids int64 (dataloader.py:21-24,28-36);
  *   - "time-major" = (T,B,F) contiguous; "batch-major" = (B,T,F) contiguous.
  */
@@ -24,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RNNT_HIP_ABI_VERSION 1
+#define RNNT_HIP_ABI_VERSION 2
 
 #define RNNT_OK 0
 #define RNNT_ERR_INVALID (-1)   /* bad argument (dims, alignment, null pointer)            */
@@ -141,6 +143,13 @@ typedef struct rnnt_lstm_desc {
   float* aux;     /* GRU backward only: (T,B,D*4H) scratch for the hidden-side gate gradients; else NULL */
   void* workspace;
   size_t workspace_bytes;
+  uint32_t* status; /* optional: caller-owned STICKY device status word (4 bytes, zeroed once by the caller).  A persistent
+                     * kernel that abandons an inter-workgroup wait (4 s bound; e.g. its workgroups lost co-residency to a
+                     * concurrent kernel) stores 1 here; the library never clears it, every later launch handed the same
+                     * word bails out at its first wait, and rnnt_hip_adamw_step_ex(guard = this word) skips the update.
+                     * Read it back with an asynchronous 4-byte copy whenever convenient (rnntransducer_amd does so once per
+                     * optimizer step, no extra synchronisation).  NULL: word 0 of the workspace, reset per launch, read by
+                     * rnnt_hip_lstm_check(). */
 } rnnt_lstm_desc;
 
 size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D);
@@ -155,7 +164,10 @@ typedef struct rnnt_lstm_bwd_desc {
   float* dw_ih[2];    /* (4H,I)  written (not accumulated) */
   float* dw_hh[2];    /* (4H,H) */
   float* db[2];       /* (G*H)  gradient of b_ih (== gradient of b_hh for LSTM / RNN) */
-  float* db_hh[2];    /* (3H)   GRU only: gradient of b_hh (differs from b_ih in the n gate); else NULL */
+  float* db_hh[2];    /* (G*H)  GRU: gradient of b_hh (differs from b_ih in the n gate), required.  LSTM / RNN: optional second
+                       * destination that receives the same values as db (grad b_hh == grad b_ih), or NULL */
+  int32_t accumulate; /* 0: dw_ih / dw_hh / db / db_hh are written; 1: added to (the outputs are views of a flat gradient
+                       * buffer that autograd would otherwise `+=` into with one extra kernel per parameter) */
 } rnnt_lstm_bwd_desc;
 
 int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* d, void* stream);
@@ -184,6 +196,15 @@ int rnnt_hip_joint_loss_fwd_bwd(const float* A, int64_t a_sb, int64_t a_st, cons
                                 const int32_t* u_lens, int32_t B, int32_t T, int32_t U1, int32_t V, int32_t blank,
                                 float gscale, float* nll, float* dA, float* dC, void* workspace,
                                 size_t workspace_bytes, void* stream);
+
+/* The same in two calls, for autograd: the forward is rnnt_hip_joint_loss_fwd_bwd with dA = dC = NULL (it leaves
+ * log-softmax terms, alpha, beta and log Z in `workspace`); this runs the gradient kernels from that workspace on the SAME
+ * A / C / bias / labels / lengths, with the upstream gradient per utterance: d(sum_b gscale * gvec[b] * nll_b)/dA,dC
+ * (gvec (B) device, or NULL = ones).  reduction="mean" of model.py:39 arrives here as gvec[b] = 1/B. */
+int rnnt_hip_joint_loss_bwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,
+                            const float* bias, const int32_t* labels, const int32_t* t_lens, const int32_t* u_lens,
+                            int32_t B, int32_t T, int32_t U1, int32_t V, int32_t blank, float gscale, const float* gvec,
+                            float* dA, float* dC, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Materialising joint for RNNTransducer.forward() (model.py:47-50): logits (B,T,U1,V) = A + C + bias. */
 int rnnt_hip_joint_logits_fwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,
@@ -216,17 +237,28 @@ int rnnt_hip_loss_from_logits_fwd_bwd_ex(const void* logits, int32_t dtype, cons
  * bias corrections from `step` >= 1). */
 int rnnt_hip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int64_t step, void* stream);
+/* Same with g scaled by `grad_scale` on load (1/world of the data-parallel average: train.py:45 DDP semantics, folded into
+ * the update instead of a separate pass over the gradients) and an optional device guard word: when *guard != 0 (the sticky
+ * LSTM status word, see rnnt_lstm_desc.status) the kernel leaves p, m, v untouched. */
+int rnnt_hip_adamw_step_ex(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int64_t step, float grad_scale, const uint32_t* guard, void* stream);
 
 /* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients: fc.bias, out_proj.bias, LSTM biases).
  * Two-stage fixed-order reduction; workspace = rnnt_hip_colsum_workspace_bytes(M, N) bytes. */
 size_t rnnt_hip_colsum_workspace_bytes(int64_t M, int64_t N);
 int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* out[n] += column sum (flat-gradient accumulation) */
+int rnnt_hip_colsum_f32_acc(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* Embedding backward (networks/decoder.py:69,102): dW[idx[m]] += dE[m] for idx[m] != padding_idx. dW (V,H)
  * must be zeroed by the caller. */
 int rnnt_hip_embedding_bwd(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V, int64_t padding_idx,
                            float* dW, void* stream);
+/* dW[v] += sum (row padding_idx untouched): accumulation into an existing gradient */
+int rnnt_hip_embedding_bwd_acc(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V, int64_t padding_idx,
+                               float* dW, void* stream);
 
 /* Greedy decoding on device (replaces JointNet.recognize_greedy, networks/transducer.py:95-145, including its
  * single-step prediction-net call networks/decoder.py:121-123 and the 1-D joint networks/transducer.py:64-69).

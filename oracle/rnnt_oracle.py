@@ -197,6 +197,19 @@ class OracleJointNet(nn.Module):
         def forward(self, tokens, lens):
             return self.out_proj(_packed_lstm(self.rnn, self.embedding(tokens), lens))
 
+        def forward_with_hidden(self, tokens, lens):
+            """decoder.py:102-126 including its second return value: the packed RNN's final states.  The reference packs
+            the batch sorted by descending length (decoder.py:105-111) and un-sorts only `outputs` (:116-120), so
+            `hidden_states` stay in that sorted batch order."""
+            x = self.embedding(tokens)
+            lens_t = torch.as_tensor(list(lens), device="cpu")
+            packed = nn.utils.rnn.pack_padded_sequence(x, lens_t, batch_first=True, enforce_sorted=False)
+            out, hidden = self.rnn(packed)                      # hidden comes back in the ORIGINAL batch order here
+            out, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=x.size(1))
+            order = torch.sort(lens_t, descending=True)[1]      # decoder.py:106
+            hidden = tuple(h[:, order] for h in hidden) if isinstance(hidden, tuple) else hidden[:, order]
+            return self.out_proj(out), hidden
+
     def __init__(self, transnet_params: dict, prednet_params: dict, num_classes: int):
         super().__init__()
         self.encoder = self._Enc(**transnet_params)

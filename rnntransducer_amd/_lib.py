@@ -33,12 +33,12 @@ class LstmDesc(C.Structure):
                 ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2), ("y", C.c_void_p),
                 ("y_drop", C.c_void_p), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
                 ("gates", C.c_void_p), ("cst", C.c_void_p), ("aux", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t)]
+                ("workspace_bytes", C.c_size_t), ("status", C.c_void_p)]
 
 
 class LstmBwdDesc(C.Structure):
     _fields_ = [("f", LstmDesc), ("dy", C.c_void_p), ("dx", C.c_void_p), ("dw_ih", C.c_void_p * 2),
-                ("dw_hh", C.c_void_p * 2), ("db", C.c_void_p * 2), ("db_hh", C.c_void_p * 2)]
+                ("dw_hh", C.c_void_p * 2), ("db", C.c_void_p * 2), ("db_hh", C.c_void_p * 2), ("accumulate", c_i32)]
 
 
 DECODE_MAX_LAYERS = 8
@@ -79,6 +79,9 @@ SYMBOLS = {
     "rnnt_hip_joint_loss_fwd_bwd": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_float,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnnt_hip_joint_loss_bwd": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_joint_logits_fwd": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, c_i64, C.c_void_p, c_i32, c_i32,
                                              c_i32, c_i32, C.c_void_p, C.c_void_p]),
     "rnnt_hip_loss_from_logits_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i32, c_i32, c_i32,
@@ -89,10 +92,14 @@ SYMBOLS = {
                                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_float, c_i64, C.c_void_p]),
+    "rnnt_hip_adamw_step_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_float, c_i64, C.c_float, C.c_void_p, C.c_void_p]),
     "rnnt_hip_embedding_fwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p]),
     "rnnt_hip_colsum_workspace_bytes": (C.c_size_t, [c_i64, c_i64]),
     "rnnt_hip_colsum_f32": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnnt_hip_colsum_f32_acc": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_embedding_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, c_i64, C.c_void_p, C.c_void_p]),
+    "rnnt_hip_embedding_bwd_acc": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, c_i32, c_i32, c_i64, C.c_void_p, C.c_void_p]),
     "rnnt_hip_greedy_decode": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
     "rnnt_hip_prednet_step": (C.c_int, [C.POINTER(PrednetStepDesc), C.c_void_p]),
     "rnnt_hip_frontend_norm_pad": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i32, c_i32, c_i64, c_i32, C.c_void_p, C.c_void_p]),

@@ -77,10 +77,14 @@ namespace {
 // path: p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void __launch_bounds__(256) adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                          float wd, float step_size, float bc2_sqrt) {
+                                                          float wd, float step_size, float bc2_sqrt, float gscale,
+                                                          const unsigned* __restrict__ guard) {
+  // guard: the persistent recurrences' sticky status word (or nullptr).  Raised = a gradient of this step may be garbage:
+  // skip the whole update (uniform branch), the host raises at its next status check.
+  if (guard && *guard != 0u) return;
   const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 + 3 < n) {
-    f32x4 pp = *reinterpret_cast<f32x4*>(p + i4), gg = *reinterpret_cast<const f32x4*>(g + i4);
+    f32x4 pp = *reinterpret_cast<f32x4*>(p + i4), gg = *reinterpret_cast<const f32x4*>(g + i4) * gscale;
     f32x4 mm = *reinterpret_cast<f32x4*>(m + i4), vv = *reinterpret_cast<f32x4*>(v + i4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -95,7 +99,7 @@ __global__ void __launch_bounds__(256) adamw_flat_kernel(float* __restrict__ p, 
   } else {
     for (long i = i4; i < n; ++i) {
       float pp = p[i] * (1.0f - lr * wd);
-      const float gg = g[i];
+      const float gg = g[i] * gscale;
       const float mm = m[i] + (gg - m[i]) * (1.0f - b1);
       const float vv = v[i] * b2 + (1.0f - b2) * gg * gg;
       pp -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
@@ -108,6 +112,12 @@ __global__ void __launch_bounds__(256) adamw_flat_kernel(float* __restrict__ p, 
 
 extern "C" int rnnt_hip_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                    float eps, float weight_decay, int64_t step, void* stream) {
+  return rnnt_hip_adamw_step_ex(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, 1.0f, nullptr, stream);
+}
+
+extern "C" int rnnt_hip_adamw_step_ex(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                      float eps, float weight_decay, int64_t step, float grad_scale, const uint32_t* guard,
+                                      void* stream) {
   using namespace rnnt;
   RNNT_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "adamw: bad arguments");
   RNNT_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
@@ -116,7 +126,7 @@ extern "C" int rnnt_hip_adamw_step(float* p, const float* g, float* m, float* v,
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   ProfScope prof(RNNT_K_MISC, 28.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)ceil_div(ceil_div(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (long)n, lr, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)sqrt(bc2));
+                     (long)n, lr, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)sqrt(bc2), grad_scale, guard);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }

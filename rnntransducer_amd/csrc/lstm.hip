@@ -1377,13 +1377,20 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd4_kernel(const LstmK p) {
 // ------------------------------------------------------------------------------------------------
 // db[d][g*H + j] = sum over the direction's (group, row) table of part[(d*rows_per_dir + r)*4H + 4j+g], fixed order
 __global__ void db_reduce_kernel(const float* __restrict__ part, int rows_per_dir, int H, int ngate, float* __restrict__ o0,
-                                 float* __restrict__ o1) {
+                                 float* __restrict__ o1, int accumulate, float* __restrict__ p0 = nullptr,
+                                 float* __restrict__ p1 = nullptr) {
   const int c = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
   if (c >= 4 * H || (c & 3) >= ngate) return;
   const float* src = part + (long)d * rows_per_dir * 4 * H + c;
   float s = 0.f;
   for (int r = 0; r < rows_per_dir; ++r) s += src[(long)r * 4 * H];
-  (d ? o1 : o0)[(c & 3) * H + (c >> 2)] = s;
+  float* o = (d ? o1 : o0) + (c & 3) * H + (c >> 2);
+  *o = accumulate ? *o + s : s;
+  float* q = d ? p1 : p0;  // optional second destination (LSTM / Elman: grad b_hh == grad b_ih)
+  if (q) {
+    q += (c & 3) * H + (c >> 2);
+    *q = accumulate ? *q + s : s;
+  }
 }
 // out[(d*4H + 4j+g)*I + k] = g < ngate ? w[d][(g*H + j)*I + k] : 0      (4 slots per unit whatever the cell type)
 __global__ void permute_w_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int H, int I, int ngate,
@@ -1398,14 +1405,21 @@ __global__ void permute_w_kernel(const float* __restrict__ w0, const float* __re
 }
 // inverse for gradients: dw[d][(g*H + j)*I + k] = in[(d*4H + 4j+g)*I + k]
 __global__ void unpermute_w_kernel(const float* __restrict__ in, int H, int I, long in_dir_stride, int ngate,
-                                   float* __restrict__ o0, float* __restrict__ o1) {
+                                   float* __restrict__ o0, float* __restrict__ o1, int accumulate, float* __restrict__ p0 = nullptr,
+                                   float* __restrict__ p1 = nullptr) {
   const long per = (long)4 * H * I;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const int d = blockIdx.y;
   if (idx >= per) return;
   const int k = (int)(idx % I), r = (int)(idx / I);
   float* o = d ? o1 : o0;
-  if ((r & 3) < ngate) o[(long)((r & 3) * H + (r >> 2)) * I + k] = in[d * in_dir_stride + idx];
+  if ((r & 3) < ngate) {
+    const long off = (long)((r & 3) * H + (r >> 2)) * I + k;
+    const float v = in[d * in_dir_stride + idx];
+    o[off] = accumulate ? o[off] + v : v;
+    float* q = d ? p1 : p0;
+    if (q) q[off] = accumulate ? q[off] + v : v;
+  }
 }
 // bias folded into the hoisted input projection: b_ih + b_hh per slot; GRU keeps b_hn out (it sits inside r * (.))
 __global__ void permute_bias_kernel(const float* __restrict__ bi0, const float* __restrict__ bh0,
@@ -1447,21 +1461,22 @@ __global__ void __launch_bounds__(256) colsum_stage1_kernel(const float* __restr
   if (r == 0 && n < N) part[(long)blockIdx.y * N + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 __global__ void __launch_bounds__(256) colsum_stage2_kernel(const float* __restrict__ part, long N, int rc,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int accumulate) {
   const long n = (long)blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
   float s = 0.f;
   for (int k = 0; k < rc; ++k) s += part[(long)k * N + n];
-  out[n] = s;
+  out[n] = accumulate ? out[n] + s : s;
 }
-int launch_colsum(const float* X, long M, long N, long ld, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_colsum(const float* X, long M, long N, long ld, float* out, void* ws, size_t ws_bytes, hipStream_t s,
+                  int accumulate = 0) {
   const int rc = colsum_chunks(M, N);
   RNNT_CHECK_ARG(ws && ws_bytes >= (size_t)rc * N * 4, "colsum: workspace too small (%zu < %zu)", ws_bytes, (size_t)rc * N * 4);
   ProfScope prof(RNNT_K_MISC, 4.0 * (double)M * (double)N, s);
   const long rows = ceil_div(M, rc);
   hipLaunchKernelGGL(colsum_stage1_kernel, dim3((unsigned)ceil_div(N, 64), rc), dim3(256), 0, s, X, M, N, ld, rows, (float*)ws);
   RNNT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, (const float*)ws, N, rc, out);
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, (const float*)ws, N, rc, out, accumulate);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }
@@ -1478,7 +1493,7 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ W, const long* __
 }
 
 __global__ void embedding_bwd_kernel(const float* __restrict__ dE, const long* __restrict__ idx, long M, int H, int V,
-                                     long pad, float* __restrict__ dW) {
+                                     long pad, float* __restrict__ dW, int accumulate) {
   // one workgroup per vocabulary row: fixed-order sum over the tokens that hit it (deterministic, no atomics)
   const int v = blockIdx.x;
   if (v == pad) return;
@@ -1486,7 +1501,7 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ dE, const long* _
     float s = 0.f;
     for (long m = 0; m < M; ++m)
       if (idx[m] == v) s += dE[m * H + h];
-    dW[(long)v * H + h] = s;
+    dW[(long)v * H + h] = accumulate ? dW[(long)v * H + h] + s : s;
   }
 }
 
@@ -1772,7 +1787,9 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->drop_thresh = (unsigned)((double)d->dropout_p * 4294967296.0);
   k->seed = d->dropout_seed;
   k->w_hh[0] = d->w_hh[0]; k->w_hh[1] = d->D > 1 ? d->w_hh[1] : d->w_hh[0];
-  k->hx = w.hx; k->status = w.flags; k->flags = w.flags + 16;
+  // status word: the caller's sticky device word when given (never reset by the library: a raised status makes every later
+  // launch bail out at its first wait and stays visible until the caller reads it), else word 0 of the workspace (reset per launch)
+  k->hx = w.hx; k->status = d->status ? d->status : w.flags; k->flags = w.flags + 16;
   k->dy = nullptr;
   k->cell = d->cell;
   k->b_hh[0] = d->b_hh[0]; k->b_hh[1] = d->D > 1 ? d->b_hh[1] : d->b_hh[0];
@@ -1930,6 +1947,12 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   const int ngate = d->cell == RNNT_CELL_LSTM ? 4 : (gru ? 3 : 1);
   RNNT_CHECK_ARG(!gru || d->aux, "lstm_bwd: GRU needs the aux buffer (T,B,D*4H)");
   for (int k = 0; k < D; ++k) RNNT_CHECK_ARG(!gru || bd->db_hh[k], "lstm_bwd: GRU needs db_hh");
+  const int acc = bd->accumulate ? 1 : 0;       // += into dw_ih / dw_hh / db / db_hh (flat-gradient views) instead of =
+  // LSTM / Elman: grad b_hh == grad b_ih; when the caller also hands db_hh it receives the same values (second destination)
+  float* twin0 = gru ? nullptr : bd->db_hh[0];
+  float* twin1 = gru ? nullptr : (D > 1 ? bd->db_hh[1] : bd->db_hh[0]);
+  if (twin0 == bd->db[0]) twin0 = nullptr;
+  if (twin1 == (D > 1 ? bd->db[1] : bd->db[0])) twin1 = nullptr;
   const float* ghid = gru ? d->aux : d->gates;  // hidden-side gate gradients (== input side except for GRU's n gate)
   RNNT_CHECK_ARG(d->x_sb == I && d->x_st == (int64_t)B * I, "lstm_bwd: x must be time-major contiguous (T,B,I)");
   for (int k = 0; k < D; ++k) RNNT_CHECK_ARG(bd->dw_ih[k] && bd->dw_hh[k] && bd->db[k], "lstm_bwd: null gradient output");
@@ -2044,7 +2067,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
     const long per = (long)4 * H * I;
     hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per, ngate,
-                       bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0]);
+                       bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0], acc);
     RNNT_CHECK_LAUNCH();
   }
   // 4. dW_hh'[d] = sum_t dG[t]^T . h_prev(t): time-shifted views of dG and y (padded frames are zero in both)
@@ -2066,28 +2089,28 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   {
     const long per = (long)4 * H * H;
     hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.dwhh, H, H, per, ngate,
-                       bd->dw_hh[0], D > 1 ? bd->dw_hh[1] : bd->dw_hh[0]);
+                       bd->dw_hh[0], D > 1 ? bd->dw_hh[1] : bd->dw_hh[0], acc);
     RNNT_CHECK_LAUNCH();
   }
   // 5. bias gradient = column sums of dG, un-permuted (the v4 recurrence already summed its own cells over time)
   if (fused_db) {
     hipLaunchKernelGGL(db_reduce_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, k.dbp, db_rows, H, ngate, bd->db[0],
-                       D > 1 ? bd->db[1] : bd->db[0]);
+                       D > 1 ? bd->db[1] : bd->db[0], acc, twin0, twin1);
     RNNT_CHECK_LAUNCH();
     if (gru) {
       hipLaunchKernelGGL(db_reduce_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, k.dbhp, db_rows, H, ngate, bd->db_hh[0],
-                         D > 1 ? bd->db_hh[1] : bd->db_hh[0]);
+                         D > 1 ? bd->db_hh[1] : bd->db_hh[0], acc);
       RNNT_CHECK_LAUNCH();
     }
   } else {
     if ((rc = launch_colsum(d->gates, (long)M, (long)N4, (long)N4, w.bp, w.scratch, w.scratch_bytes, s))) return rc;
     hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, w.bp, H, 1, (long)4 * H, ngate,
-                       bd->db[0], D > 1 ? bd->db[1] : bd->db[0]);
+                       bd->db[0], D > 1 ? bd->db[1] : bd->db[0], acc, twin0, twin1);
     RNNT_CHECK_LAUNCH();
     if (gru) {  // b_hh sees the hidden-side gradients (n gate scaled by r)
       if ((rc = launch_colsum(ghid, (long)M, (long)N4, (long)N4, w.bp, w.scratch, w.scratch_bytes, s))) return rc;
       hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(4 * H, 256), D), dim3(256), 0, s, w.bp, H, 1, (long)4 * H, ngate,
-                         bd->db_hh[0], D > 1 ? bd->db_hh[1] : bd->db_hh[0]);
+                         bd->db_hh[0], D > 1 ? bd->db_hh[1] : bd->db_hh[0], acc);
       RNNT_CHECK_LAUNCH();
     }
   }
@@ -2129,6 +2152,11 @@ extern "C" int rnnt_hip_colsum_f32(const float* X, int64_t M, int64_t N, int64_t
   RNNT_CHECK_ARG(X && out && M >= 0 && N >= 1 && ld >= N, "colsum: bad arguments");
   return launch_colsum(X, (long)M, (long)N, (long)ld, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
+extern "C" int rnnt_hip_colsum_f32_acc(const float* X, int64_t M, int64_t N, int64_t ld, float* out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  RNNT_CHECK_ARG(X && out && M >= 0 && N >= 1 && ld >= N, "colsum: bad arguments");
+  return launch_colsum(X, (long)M, (long)N, (long)ld, out, workspace, workspace_bytes, (hipStream_t)stream, 1);
+}
 
 extern "C" int rnnt_hip_embedding_fwd(const float* W, const int64_t* idx, int64_t M, int32_t H, int32_t V, float* out,
                                       void* stream) {
@@ -2141,11 +2169,19 @@ extern "C" int rnnt_hip_embedding_fwd(const float* W, const int64_t* idx, int64_
   return RNNT_OK;
 }
 
-extern "C" int rnnt_hip_embedding_bwd(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V,
-                                      int64_t padding_idx, float* dW, void* stream) {
+static int embedding_bwd_impl(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V, int64_t padding_idx,
+                              float* dW, int accumulate, void* stream) {
   RNNT_CHECK_ARG(dE && idx && dW && M >= 0 && H >= 1 && V >= 1, "embedding_bwd: bad arguments");
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, dE, (const long*)idx, (long)M, H, V,
-                     (long)padding_idx, dW);
+                     (long)padding_idx, dW, accumulate);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
+}
+extern "C" int rnnt_hip_embedding_bwd(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V,
+                                      int64_t padding_idx, float* dW, void* stream) {
+  return embedding_bwd_impl(dE, idx, M, H, V, padding_idx, dW, 0, stream);
+}
+extern "C" int rnnt_hip_embedding_bwd_acc(const float* dE, const int64_t* idx, int64_t M, int32_t H, int32_t V,
+                                          int64_t padding_idx, float* dW, void* stream) {
+  return embedding_bwd_impl(dE, idx, M, H, V, padding_idx, dW, 1, stream);
 }

@@ -36,6 +36,8 @@ class RNNTransducer(_Base):
         if pl is not None:
             self.save_hyperparameters(prednet_params, transnet_params, jointnet_params, args)
         self.args = args
+        self._ctor_args = {"prednet_params": dict(prednet_params), "transnet_params": dict(transnet_params),
+                           "jointnet_params": dict(jointnet_params), "args": args}
         prednet_params = dict(prednet_params)
         blank = getattr(args, "blank_token_id", None)
         if blank is None:
@@ -54,12 +56,53 @@ class RNNTransducer(_Base):
             raise ValueError(f"text_lengths must lie in [1, {input_texts.size(1)}]")
         return self.jointnet(input_audios, audio_lengths, input_texts, text_lengths)
 
+    # ---- checkpoint wire format -------------------------------------------------------------------
+    @staticmethod
+    def read_reference_checkpoint(path: str) -> dict:
+        """Reads a Lightning .ckpt as the reference trainer writes it (train.py:31-37 ModelCheckpoint; `save_hyperparameters`
+        at model.py:22 stores the three parameter dicts AND the `argparse.Namespace` under `hyper_parameters`).  Weights-only
+        unpickling: nothing from the file is executed; `argparse.Namespace` — a plain attribute container — is the one
+        extra class allowed."""
+        with torch.serialization.safe_globals([Namespace]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+
     def load_reference_checkpoint(self, path: str, strict: bool = True):
-        """Loads the `state_dict` of a Lightning .ckpt written by the reference trainer (train.py:31-37; keys
-        `jointnet.*`).  Uses torch.load(weights_only=True): nothing from the file is executed."""
-        blob = torch.load(path, map_location="cpu", weights_only=True)
+        """Loads the `state_dict` (keys `jointnet.*`) of a reference-written Lightning .ckpt into this module."""
+        blob = self.read_reference_checkpoint(path)
         sd = blob.get("state_dict", blob)
         return self.load_state_dict({k: v for k, v in sd.items() if k.startswith("jointnet.")}, strict=strict)
+
+    @classmethod
+    def from_reference_checkpoint(cls, path: str, **overrides):
+        """`RNNTransducer.load_from_checkpoint(path, prednet_params=..., ...)` of inference.py:19-25 without Lightning:
+        constructor arguments come from the file's `hyper_parameters` unless overridden."""
+        blob = cls.read_reference_checkpoint(path)
+        hp = dict(blob.get("hyper_parameters", {}))
+        hp.update(overrides)
+        model = cls(hp["prednet_params"], hp["transnet_params"], hp["jointnet_params"], hp["args"])
+        sd = blob["state_dict"]
+        model.load_state_dict({k: v for k, v in sd.items() if k.startswith("jointnet.")})
+        return model
+
+    def save_reference_checkpoint(self, path: str, epoch: int = 0, global_step: int = 0, optimizer=None) -> None:
+        """Writes a Lightning-1.8-shaped .ckpt the reference's `load_from_checkpoint` / `--resume_from_checkpoint` accept:
+        `state_dict` (CPU tensors, keys `jointnet.*`), `hyper_parameters` = what model.py:22 saves (three dicts + the
+        Namespace), epoch / global_step, `optimizer_states` in torch's format when an optimizer is given."""
+        jp = dict(self._ctor_args["jointnet_params"])
+        blob = {
+            "epoch": int(epoch), "global_step": int(global_step), "pytorch-lightning_version": "1.8.0",
+            "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+            "hyper_parameters": {"prednet_params": dict(self._ctor_args["prednet_params"]),
+                                 "transnet_params": dict(self._ctor_args["transnet_params"]), "jointnet_params": jp,
+                                 "args": self._ctor_args["args"]},
+            "hparams_name": "kwargs",
+        }
+        if optimizer is not None:
+            osd = optimizer.state_dict()
+            osd["state"] = {k: {n: (t.detach().cpu().clone() if isinstance(t, torch.Tensor) else t) for n, t in st.items()}
+                            for k, st in osd["state"].items()}
+            blob["optimizer_states"] = [osd]
+        torch.save(blob, path)
 
     def training_step(self, batch, batch_idx):
         assert not getattr(self.args, "move_metrics_to_cpu", False), "DDP only (model.py:53)"
@@ -112,13 +155,18 @@ class RNNTransducer(_Base):
 
     def configure_optimizers(self):
         group = [{"params": [p for p in self.parameters()], "name": "OneCycleLR"}]
+        trainer = getattr(self, "_trainer", None)
         if next(self.parameters()).is_cuda:
-            # same optimiser, same hyper-parameters: parameters/gradients/moments flattened, one fused HIP step
+            # same optimiser, same hyper-parameters: parameters/gradients/moments flattened, one fused HIP step.
+            # direct_grads (backward kernels add into the flat gradient views, no autograd accumulation kernels) is for loops
+            # that use FlatAdamW.all_reduce_grads() as the DP exchange; under a Lightning trainer / DistributedDataParallel the
+            # reducer needs autograd's accumulation hooks, so it stays off there.  args.direct_flat_grads overrides.
             from .optim import FlatAdamW
-            optimizer = FlatAdamW(group, lr=self.args.learning_rate, weight_decay=self.args.weight_decay)
+            direct = getattr(self.args, "direct_flat_grads", None)
+            direct = (trainer is None) if direct is None else bool(direct)
+            optimizer = FlatAdamW(group, lr=self.args.learning_rate, weight_decay=self.args.weight_decay, direct_grads=direct)
         else:
             optimizer = torch.optim.AdamW(group, lr=self.args.learning_rate, weight_decay=self.args.weight_decay)
-        trainer = getattr(self, "_trainer", None)
         total = trainer.estimated_stepping_batches if trainer is not None else int(getattr(self.args, "total_steps"))
         scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=self.args.learning_rate, total_steps=total,
                                                         pct_start=self.args.warmup_ratio,

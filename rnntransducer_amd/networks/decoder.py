@@ -42,14 +42,23 @@ class TextPredNet(nn.Module):
         return self.out_proj(self.rnn(emb, lens_dev))
 
     def forward(self, inputs: torch.Tensor, input_lengths=None, prev_hidden_state=None):
-        """Training branch (input_lengths given): (B,U1) tokens -> ((B,U1,O), None).
+        """Training branch (input_lengths given): (B,U1) tokens -> ((B,U1,O), hidden_states) with hidden_states what the
+        reference's packed `self.rnn(...)` returns (decoder.py:115,126): the (L,B,H) states after each sequence's own last
+        token — (h_n, c_n) for LSTM, h_n otherwise — in the reference's LENGTH-SORTED batch order (it packs the batch sorted by
+        descending length at decoder.py:105-111 and only un-sorts `outputs`, :116-120).
         Step branch (input_lengths None, decoder.py:121-123): (B,S) tokens fed one column at a time from `prev_hidden_state`
         (None = zeros; LSTM: a (h, c) tuple of (L,B,H) tensors, GRU / RNN: h) -> ((B,S,O), new hidden state in torch's format)."""
         if input_lengths is not None:
             if prev_hidden_state is not None:
                 raise ValueError("prev_hidden_state goes with the step branch (input_lengths=None), as in decoder.py:102-123")
             lens = lengths_to_device(input_lengths, inputs.device)
-            return self.forward_time_major(inputs, lens).transpose(0, 1).contiguous(), None
+            emb = self.embedding(inputs.transpose(0, 1).contiguous())
+            y, h_n, c_n = self.rnn(emb, lens, want_final=True)
+            lens_cpu = input_lengths.detach().cpu() if isinstance(input_lengths, torch.Tensor) else torch.tensor(list(input_lengths))
+            order = torch.sort(lens_cpu, descending=True)[1].to(inputs.device)  # decoder.py:106
+            h_n = h_n.index_select(1, order)
+            hidden = (h_n, c_n.index_select(1, order)) if self.rnn.CELL == 0 else h_n
+            return self.out_proj(y).transpose(0, 1).contiguous(), hidden
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("the step branch is inference-only: call it under torch.no_grad()")
         lstm = self.rnn.CELL == 0

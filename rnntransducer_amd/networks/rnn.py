@@ -49,8 +49,9 @@ class HipLSTM(nn.Module):
                     out.append(getattr(self, f"{name}_l{layer}{suffix}"))
         return out
 
-    def forward(self, x_tm: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
-        """x_tm (T,B,I) time-major fp32, lens (B) int32 on the same device -> (T,B,D*H), zeros for t >= lens[b]."""
+    def forward(self, x_tm: torch.Tensor, lens: torch.Tensor, want_final: bool = False):
+        """x_tm (T,B,I) time-major fp32, lens (B) int32 on the same device -> (T,B,D*H), zeros for t >= lens[b].
+        want_final: -> (y, h_n, c_n) with the (L*D, B, H) states after each sequence's own last step (c_n empty unless LSTM)."""
         p = self.dropout if (self.training and self.num_layers > 1) else 0.0
         self._step += 1
         seed = (torch.initial_seed() * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFFFFFF
@@ -60,14 +61,16 @@ class HipLSTM(nn.Module):
             raise _lib.RnntHipError(f"hidden_size={self.hidden_size} does not fit the persistent recurrence kernels")
         if B <= cap:
             return LstmStackFn.apply(x_tm, lens, self.hidden_size, self.num_layers, self.bidirectional, p, seed, self.CELL,
-                                     *self.flat_weights())
+                                     want_final, *self.flat_weights())
         # batch rows are independent: run slices of the batch back to back (autograd sums the weight gradients)
         outs = []
         for b0 in range(0, B, cap):
             outs.append(LstmStackFn.apply(x_tm[:, b0:b0 + cap].contiguous(), lens[b0:b0 + cap].contiguous(), self.hidden_size,
                                           self.num_layers, self.bidirectional, p, seed + 104729 * (b0 + 1), self.CELL,
-                                          *self.flat_weights()))
-        return torch.cat(outs, dim=1)
+                                          want_final, *self.flat_weights()))
+        if not want_final:
+            return torch.cat(outs, dim=1)
+        return tuple(torch.cat([o[i] for o in outs], dim=1) for i in range(3))
 
 
 class HipGRU(HipLSTM):

@@ -54,7 +54,7 @@ class JointNet(nn.Module):
         u_lens = lengths_to_device(target_lengths, dev)
         enc = self.encoder.forward_time_major(input_audios, t_lens)
         dec = self.decoder.forward_time_major(input_texts, u_lens + 1)  # text length = label length + 1 (dataloader.py:39-40)
-        return JointLossFn.apply(enc, dec, self.fc.weight, self.fc.bias, targets, t_lens, u_lens, blank)
+        return JointLossFn.apply(enc, dec, self.fc.weight, self.fc.bias, targets, t_lens, u_lens, blank, torch.is_grad_enabled())
 
     @torch.no_grad()
     def recognize_greedy(self, inputs: torch.Tensor, inputs_lengths, blank_token_id: int, max_iters: int = 3,

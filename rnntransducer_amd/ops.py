@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import GEMM_GELU_A, GEMM_GELU_B, GEMM_MUL_DGELU, GemmDesc, LstmBwdDesc, LstmDesc, RnntHipError, check
+from ._lib import GEMM_ACCUM, GEMM_GELU_A, GEMM_GELU_B, GEMM_MUL_DGELU, GemmDesc, LstmBwdDesc, LstmDesc, RnntHipError, check
 
 BIG = 1 << 40  # "no second level" divisor for the GEMM row maps
 
@@ -37,6 +37,50 @@ def _addr(t: Optional[torch.Tensor], elem_off: int = 0) -> Optional[int]:
     if t is None:
         return None
     return t.data_ptr() + elem_off * t.element_size()
+
+
+# --------------------------------------------------------------------------------------------------
+# flat-gradient targets (optim.FlatAdamW(direct_grads=True) tags its parameters): backward kernels then ADD their weight
+# gradients straight into the parameter's `.grad` view of the flat buffer and hand autograd `None`, instead of returning
+# a fresh tensor that autograd would `+=` into the view with one extra kernel per parameter.
+# --------------------------------------------------------------------------------------------------
+def _direct_grad(param: torch.Tensor) -> Optional[torch.Tensor]:
+    g = param.grad if getattr(param, "_rnnt_direct_grad", False) else None
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != param.shape:
+        return None
+    return g
+
+
+# --------------------------------------------------------------------------------------------------
+# sticky status word of the persistent recurrences (include/rnnt_hip.h: rnnt_lstm_desc.status), one per device.
+# Kernels raise it when an inter-workgroup wait is abandoned; nothing in the library clears it.  FlatAdamW hands it to
+# the update kernel as a guard and reads it back asynchronously once per step; `lstm_status_check` is the explicit read.
+# --------------------------------------------------------------------------------------------------
+_STATUS = {}
+
+
+def lstm_status_word(device) -> torch.Tensor:
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    w = _STATUS.get(idx)
+    if w is None:
+        w = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", idx))
+        _STATUS[idx] = w
+    return w
+
+
+def lstm_status_check(device=None) -> None:
+    """Synchronous read of the device's sticky status word; raises RnntHipError if a persistent LSTM kernel gave up on an
+    inter-workgroup wait (its outputs, and every later LSTM launch on this device, are invalid).  Clears the word so a
+    caller that handles the exception can go on."""
+    for idx, w in list(_STATUS.items()):
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        if int(w[0].item()) != 0:
+            w.zero_()
+            raise RnntHipError("a persistent LSTM kernel abandoned an inter-workgroup wait (its workgroups were not "
+                               "co-resident for 4 s — is another kernel holding the CUs?): activations and gradients "
+                               "of that step are invalid; the guarded AdamW update was skipped")
 
 
 # --------------------------------------------------------------------------------------------------
@@ -70,13 +114,14 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, B: torch.Tensor, Cout: torch.T
     check(_lib.lib().rnnt_hip_gemm_f32(C.byref(d), _stream()), "rnnt_hip_gemm_f32")
 
 
-def colsum(X: torch.Tensor, M: int, N: int, ld: Optional[int] = None) -> torch.Tensor:
-    out = torch.empty(N, device=X.device, dtype=torch.float32)
+def colsum(X: torch.Tensor, M: int, N: int, ld: Optional[int] = None, into: Optional[torch.Tensor] = None):
+    """Column sums of X (M,N).  `into`: add them to this (N,) tensor (a flat-gradient view) and return None."""
+    out = torch.empty(N, device=X.device, dtype=torch.float32) if into is None else into
     nws = _lib.lib().rnnt_hip_colsum_workspace_bytes(M, N)
     ws = torch.empty(max(nws, 16), device=X.device, dtype=torch.uint8)
-    check(_lib.lib().rnnt_hip_colsum_f32(_addr(X), M, N, N if ld is None else ld, _addr(out), _addr(ws), nws, _stream()),
-          "colsum")
-    return out
+    fn = _lib.lib().rnnt_hip_colsum_f32 if into is None else _lib.lib().rnnt_hip_colsum_f32_acc
+    check(fn(_addr(X), M, N, N if ld is None else ld, _addr(out), _addr(ws), nws, _stream()), "colsum")
+    return out if into is None else None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -87,14 +132,15 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, W, bias):
         _need_gpu(x, W, bias)
         x = _f32c(x, "x")
-        W = _f32c(W, "weight")
+        W0 = _f32c(W, "weight")
         lead, K = x.shape[:-1], x.shape[-1]
         N = W.shape[0]
         M = x.numel() // K
         y = torch.empty(*lead, N, device=x.device, dtype=torch.float32)
-        gemm(M, N, K, x, W, y, bias=bias)
-        ctx.save_for_backward(x, W)
+        gemm(M, N, K, x, W0, y, bias=bias)
+        ctx.save_for_backward(x, W0)
         ctx.has_bias = bias is not None
+        ctx.w_param, ctx.b_param = W, bias  # the Parameter objects themselves (for their flat .grad views)
         return y
 
     @staticmethod
@@ -108,10 +154,12 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             gemm(M, K, N, dy, W, dx, b_sn=1, b_sk=K)          # dx = dy . W
         if ctx.needs_input_grad[1]:
-            dW = torch.empty_like(W)
-            gemm(N, K, M, dy, x, dW, a_mc=True, a_sk=N, b_sn=1, b_sk=K, split_k=True)  # dW = dy^T . x
+            tgt = _direct_grad(ctx.w_param)
+            dW = torch.empty_like(W) if tgt is None else None
+            gemm(N, K, M, dy, x, dW if tgt is None else tgt, a_mc=True, a_sk=N, b_sn=1, b_sk=K, split_k=True,
+                 flags=0 if tgt is None else GEMM_ACCUM)  # dW = dy^T . x
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy, M, N)
+            db = colsum(dy, M, N, into=_direct_grad(ctx.b_param))
         return dx, dW, db
 
 
@@ -122,6 +170,7 @@ class EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, idx, padding_idx):
         _need_gpu(W, idx)
+        W_param = W
         W = _f32c(W, "embedding.weight")
         if idx.dtype != torch.int64:
             raise ValueError(f"token ids must be int64 (dataloader.py:28-36), got {idx.dtype}")
@@ -132,6 +181,7 @@ class EmbeddingFn(torch.autograd.Function):
         ctx.save_for_backward(idx)
         ctx.shape = (V, H)
         ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        ctx.w_param = W_param
         return out
 
     @staticmethod
@@ -139,6 +189,11 @@ class EmbeddingFn(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         V, H = ctx.shape
         dE = _f32c(dE, "dE")
+        tgt = _direct_grad(ctx.w_param)
+        if tgt is not None:
+            check(_lib.lib().rnnt_hip_embedding_bwd_acc(_addr(dE), _addr(idx), idx.numel(), H, V, ctx.padding_idx, _addr(tgt),
+                                                        _stream()), "embedding_bwd_acc")
+            return None, None, None
         dW = torch.zeros(V, H, device=dE.device, dtype=torch.float32)
         check(_lib.lib().rnnt_hip_embedding_bwd(_addr(dE), _addr(idx), idx.numel(), H, V, ctx.padding_idx, _addr(dW),
                                                 _stream()), "embedding_bwd")
@@ -174,18 +229,22 @@ def _fill_lstm_desc(d: LstmDesc, T, B, I, H, D, lens, x, weights, y, y_drop, p, 
     d.cst = _addr(cst)
     d.workspace = _addr(ws)
     d.workspace_bytes = ws.numel()
+    d.status = _addr(lstm_status_word(ws.device))
 
 
 class LstmStackFn(torch.autograd.Function):
     """x (T,B,I) time-major, lens (B) int32 on device -> y (T,B,D*H); zero rows for t >= lens[b].
-    `cell`: 0 LSTM, 1 GRU, 2 tanh-RNN, 3 ReLU-RNN (the reference's supported_rnns, encoder.py:48-52)."""
+    `cell`: 0 LSTM, 1 GRU, 2 tanh-RNN, 3 ReLU-RNN (the reference's supported_rnns, encoder.py:48-52).
+    `want_final`: also return (h_n, c_n) — (L*D, B, H) states after each sequence's own last step, what torch's RNN modules
+    return next to the output (decoder.py:115); not differentiable here (the reference never differentiates through them)."""
 
     @staticmethod
-    def forward(ctx, x, lens, hidden, num_layers, bidirectional, dropout_p, seed, cell, *weights):
+    def forward(ctx, x, lens, hidden, num_layers, bidirectional, dropout_p, seed, cell, want_final, *weights):
         _need_gpu(x, lens, *weights)
         if lens.dtype != torch.int32:
             raise ValueError(f"lengths must be int32 (dataloader.py:23-24), got {lens.dtype}")
         x = _f32c(x, "x")
+        params = weights
         weights = [_f32c(w, "lstm weight") for w in weights]
         T, B, I0 = x.shape
         D = 2 if bidirectional else 1
@@ -212,15 +271,35 @@ class LstmStackFn(torch.autograd.Function):
         ctx.ws = ws
         ctx.saved = saved
         ctx.weights = weights
+        ctx.params = params
         ctx.x_needs_grad = x.requires_grad
-        return cur
+        if not want_final:
+            return cur
+        # final states: plumbing gathers from the stash (forward direction: frame lens-1, reverse direction: frame 0)
+        last = (lens.long() - 1).clamp_(min=0)
+        rows = torch.arange(B, device=dev)
+        hs, cs = [], []
+        for (_, y, _, cst, _) in saved:
+            yv = y.view(T, B, D, H)
+            cv = cst.view(D, T, H // 4, B, 4) if cst is not None else None
+            for dd in range(D):
+                tsel = last if dd == 0 else torch.zeros_like(last)
+                hs.append(yv[tsel, rows, dd])
+                if cv is not None:
+                    cs.append(cv[dd, tsel, :, rows, :].reshape(B, H))
+        h_n = torch.stack(hs)
+        c_n = torch.stack(cs) if cs else torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(h_n, c_n)
+        return cur, h_n, c_n
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         T, B, H, D, L, seed, cell = ctx.meta
         dy = _f32c(dy, "dy")
         weights = ctx.weights
         grads: List[Optional[torch.Tensor]] = [None] * len(weights)
+        targets = [_direct_grad(p) for p in ctx.params]
+        direct = all(t is not None for t in targets)  # all-or-nothing per stack: one accumulate flag per launch
         dx = None
         for layer in range(L - 1, -1, -1):
             x_l, y_l, gates, cst, p = ctx.saved[layer]
@@ -234,23 +313,29 @@ class LstmStackFn(torch.autograd.Function):
             need_dx = layer > 0 or ctx.x_needs_grad
             dx = torch.empty(T, B, I, device=dy.device, dtype=torch.float32) if need_dx else None
             bd.dx = _addr(dx)
+            bd.accumulate = 1 if direct else 0
             for k in range(D):
+                base = 4 * D * layer + 4 * k
+                if direct:  # += straight into the flat-gradient views; b_hh's view is the second destination of db
+                    bd.dw_ih[k], bd.dw_hh[k] = _addr(targets[base]), _addr(targets[base + 1])
+                    bd.db[k], bd.db_hh[k] = _addr(targets[base + 2]), _addr(targets[base + 3])
+                    continue
                 dw_ih = torch.empty_like(wl[4 * k])
                 dw_hh = torch.empty_like(wl[4 * k + 1])
                 db = torch.empty_like(wl[4 * k + 2])
                 db_hh = torch.empty_like(db) if cell == 1 else db  # GRU: b_hn sits inside r * (.), its gradient differs
                 bd.dw_ih[k], bd.dw_hh[k], bd.db[k] = _addr(dw_ih), _addr(dw_hh), _addr(db)
                 bd.db_hh[k] = _addr(db_hh) if cell == 1 else None
-                base = 4 * D * layer + 4 * k
                 grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dw_ih, dw_hh, db, db_hh
             check(_lib.lib().rnnt_hip_lstm_bwd(C.byref(bd), _stream()), "rnnt_hip_lstm_bwd")
             dy = dx
         ctx.saved = None  # release the stash
-        return (dx if ctx.x_needs_grad else None, None, None, None, None, None, None, None, *grads)
+        return (dx if ctx.x_needs_grad else None, None, None, None, None, None, None, None, None, *grads)
 
 
 def lstm_check(ws: torch.Tensor) -> None:
-    """Raises if a persistent LSTM kernel abandoned an inter-workgroup wait (synchronises the stream)."""
+    """C-ABI diagnostic for callers that pass status = NULL (the workspace's own per-launch word); the package itself uses
+    the sticky device word: see lstm_status_check()."""
     check(_lib.lib().rnnt_hip_lstm_check(_addr(ws), _stream()), "rnnt_hip_lstm_check")
 
 
@@ -268,8 +353,9 @@ def _joint_ac(enc, dec, W, Oe, Od, V):
     return A, Cm
 
 
-def _joint_backward(enc, dec, W, dA, dC, needs):
-    """d_enc, d_dec, dW, db from dA (T,B,V), dC (U1,B,V)."""
+def _joint_backward(enc, dec, W, dA, dC, needs, w_tgt=None, b_tgt=None):
+    """d_enc, d_dec, dW, db from dA (T,B,V), dC (U1,B,V).  w_tgt / b_tgt: flat-gradient views to add into (then None is
+    returned for that gradient)."""
     T, B, Oe = enc.shape
     U1, _, Od = dec.shape
     V = W.shape[0]
@@ -282,22 +368,27 @@ def _joint_backward(enc, dec, W, dA, dC, needs):
         d_dec = torch.empty_like(dec)
         gemm(U1 * B, Od, V, dC, W, d_dec, b_off=Oe, b_sn=1, b_sk=O, aux=dec, flags=GEMM_MUL_DGELU)
     if needs[2]:
-        dW = torch.empty_like(W)
-        gemm(V, Oe, T * B, dA, enc, dW, a_mc=True, a_sk=V, b_sn=1, b_sk=Oe, c_div=1, c_so=O, c_si=0, flags=GEMM_GELU_B,
+        dW = torch.empty_like(W) if w_tgt is None else None
+        out = dW if w_tgt is None else w_tgt
+        fl = GEMM_GELU_B | (0 if w_tgt is None else GEMM_ACCUM)
+        gemm(V, Oe, T * B, dA, enc, out, a_mc=True, a_sk=V, b_sn=1, b_sk=Oe, c_div=1, c_so=O, c_si=0, flags=fl, split_k=True)
+        gemm(V, Od, U1 * B, dC, dec, out, a_mc=True, a_sk=V, b_sn=1, b_sk=Od, c_off=Oe, c_div=1, c_so=O, c_si=0, flags=fl,
              split_k=True)
-        gemm(V, Od, U1 * B, dC, dec, dW, a_mc=True, a_sk=V, b_sn=1, b_sk=Od, c_off=Oe, c_div=1, c_so=O, c_si=0,
-             flags=GEMM_GELU_B, split_k=True)
     if needs[3]:
-        db = colsum(dA, T * B, V)
+        db = colsum(dA, T * B, V, into=b_tgt)
     return d_enc, d_dec, dW, db
 
 
 class JointLossFn(torch.autograd.Function):
-    """enc (T,B,Oe), dec (U1,B,Od) time-major -> per-utterance NLL (B,).  Never builds (B,T,U1,V)."""
+    """enc (T,B,Oe), dec (U1,B,Od) time-major -> per-utterance NLL (B,).  Never builds (B,T,U1,V).
+    forward: A/C pre-GEMMs + log-softmax terms + alpha/beta (kept in a workspace); backward: the lattice gradient kernel with
+    the upstream per-utterance gradient folded in (1/B under reduction="mean", model.py:39), then the joint's own backward.
+    Under torch.no_grad() (validation_step) no gradient kernel runs and nothing is kept."""
 
     @staticmethod
-    def forward(ctx, enc, dec, W, bias, labels, t_lens, u_lens, blank):
+    def forward(ctx, enc, dec, W, bias, labels, t_lens, u_lens, blank, want_grad=True):
         _need_gpu(enc, dec, W, bias, labels, t_lens, u_lens)
+        w_param, b_param = W, bias
         enc, dec, W, bias = _f32c(enc, "enc"), _f32c(dec, "dec"), _f32c(W, "fc.weight"), _f32c(bias, "fc.bias")
         for name, t in (("targets", labels), ("frame lengths", t_lens), ("target lengths", u_lens)):
             if t.dtype != torch.int32:
@@ -311,24 +402,32 @@ class JointLossFn(torch.autograd.Function):
                              f"targets {tuple(labels.shape)}")
         A, Cm = _joint_ac(enc, dec, W, Oe, Od, V)
         nll = torch.empty(B, device=enc.device, dtype=torch.float32)
-        dA, dC = torch.empty_like(A), torch.empty_like(Cm)
         nws = _lib.lib().rnnt_hip_joint_loss_workspace_bytes(B, T, U1, V)
         ws = torch.empty(nws, device=enc.device, dtype=torch.uint8)
         check(_lib.lib().rnnt_hip_joint_loss_fwd_bwd(_addr(A), V, B * V, _addr(Cm), V, B * V, _addr(bias), _addr(labels),
                                                      _addr(t_lens), _addr(u_lens), B, T, U1, V, int(blank), 1.0,
-                                                     _addr(nll), _addr(dA), _addr(dC), _addr(ws), nws, _stream()),
+                                                     _addr(nll), None, None, _addr(ws), nws, _stream()),
               "rnnt_hip_joint_loss_fwd_bwd")
-        ctx.save_for_backward(enc, dec, W, dA, dC)
+        if want_grad and any(ctx.needs_input_grad[:4]):  # want_grad: the caller's torch.is_grad_enabled() (always off in here)
+            ctx.save_for_backward(enc, dec, W, bias, labels, t_lens, u_lens, A, Cm, ws)
+            ctx.blank = int(blank)
+            ctx.w_param, ctx.b_param = w_param, b_param
         return nll
 
     @staticmethod
     def backward(ctx, g):
-        enc, dec, W, dA, dC = ctx.saved_tensors
-        gb = g.to(torch.float32).view(1, -1, 1)
-        dA = dA * gb  # per-utterance upstream gradient (1/B for reduction="mean", model.py:39)
-        dC = dC * gb
-        d_enc, d_dec, dW, db = _joint_backward(enc, dec, W, dA, dC, ctx.needs_input_grad[:4])
-        return d_enc, d_dec, dW, db, None, None, None, None
+        enc, dec, W, bias, labels, t_lens, u_lens, A, Cm, ws = ctx.saved_tensors
+        T, B, _ = enc.shape
+        U1, V = dec.shape[0], W.shape[0]
+        gvec = _f32c(g.to(torch.float32), "grad of nll")
+        dA, dC = torch.empty_like(A), torch.empty_like(Cm)
+        check(_lib.lib().rnnt_hip_joint_loss_bwd(_addr(A), V, B * V, _addr(Cm), V, B * V, _addr(bias), _addr(labels),
+                                                 _addr(t_lens), _addr(u_lens), B, T, U1, V, ctx.blank, 1.0, _addr(gvec),
+                                                 _addr(dA), _addr(dC), _addr(ws), ws.numel(), _stream()),
+              "rnnt_hip_joint_loss_bwd")
+        d_enc, d_dec, dW, db = _joint_backward(enc, dec, W, dA, dC, ctx.needs_input_grad[:4],
+                                               _direct_grad(ctx.w_param), _direct_grad(ctx.b_param))
+        return d_enc, d_dec, dW, db, None, None, None, None, None
 
 
 class JointLogitsFn(torch.autograd.Function):

@@ -1,61 +1,168 @@
-"""FlatAdamW — torch.optim.AdamW (what the reference configures at model.py:111-115) with every parameter, gradient and
-moment of the module living in ONE flat fp32 buffer each:
+"""FlatParams / FlatAdamW — the optimiser and the data-parallel exchange of the hot path on flat fp32 buffers.
 
-  * `p.data` / `p.grad` become views into `flat_param` / `flat_grad`, so autograd accumulates straight into the flat
-    gradient buffer, the data-parallel exchange is a single RCCL all-reduce over it (dist.py), and
-  * `step()` is ONE fused HIP kernel (`rnnt_hip_adamw_step`) instead of torch's multi-tensor passes.
+`FlatParams` (device-agnostic: it also builds on CPU tensors, which is how the world-2 gloo test runs the very code the GPU
+path ships) lays every trainable parameter and its gradient out back to back in ONE buffer each:
 
-It stays a `torch.optim.AdamW` subclass: `param_groups` (so OneCycleLR drives `lr` exactly as in the reference),
-`state_dict()` (per-parameter `exp_avg` / `exp_avg_sq` are views into the flat moments) and `zero_grad()` keep working.
+  * `p.data` / `p.grad` become views into `flat_param` / `flat_grad`;
+  * the data-parallel exchange (`all_reduce_grads`, replacing Lightning's DDPStrategy -> DistributedDataParallel bucketed NCCL
+    all-reduce of train.py:45 / scripts/run_train.sh:9,26) is ONE collective over `flat_grad` — RCCL over xGMI on the GPU
+    (config 2: 24.3 M parameters = 97.3 MB), SUM over ranks; the x 1/world of DDP's average is folded into the update kernel;
+  * with `direct_grads=True` the backward kernels add weight gradients straight into the views (ops._direct_grad) instead
+    of returning tensors that autograd would `+=` with one extra kernel per parameter.  Leave it off when
+    torch.nn.parallel.DistributedDataParallel wraps the module: DDP's reducer listens to autograd's accumulation hooks.
+
+`FlatAdamW` = torch.optim.AdamW (what the reference configures at model.py:111-115: same hyper-parameters, `param_groups` so
+OneCycleLR drives `lr` exactly as in the reference, `state_dict()` / `load_state_dict()` in torch's format) whose `step()` is ONE
+fused HIP kernel over the flat buffers (`rnnt_hip_adamw_step_ex`), guarded on device by the persistent recurrences' sticky
+status word: if an LSTM kernel of this step gave up on an inter-workgroup wait, the update is skipped on device and the next
+`step()` raises RnntHipError — no host synchronisation on the way (one 4-byte asynchronous read-back per step).
 """
-from typing import Iterable
+from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
 from . import _lib
-from .ops import _addr, _stream
+
+
+class FlatParams:
+    def __init__(self, params: Iterable[torch.nn.Parameter], direct_grads: bool = False):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise _lib.RnntHipError("FlatParams needs all parameters in float32 on one device (move the module first)")
+        self.sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]  # keep every view 16-byte aligned
+        self.offsets = [0]
+        for n in self.sizes[:-1]:
+            self.offsets.append(self.offsets[-1] + n)
+        total = sum(self.sizes)
+        self.flat_param = torch.zeros(total, device=dev)
+        self.flat_grad = torch.zeros(total, device=dev)
+        self.direct_grads = bool(direct_grads)
+        for p, off in zip(self.params, self.offsets):
+            self.flat_param[off:off + p.numel()].copy_(p.data.reshape(-1))
+        self.adopt()
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def view(self, flat: torch.Tensor, i: int) -> torch.Tensor:
+        p, off = self.params[i], self.offsets[i]
+        return flat[off:off + p.numel()].view_as(p)
+
+    def adopt(self) -> None:
+        """(Re)points every parameter's .data / .grad at its slice of the flat buffers.  A gradient found elsewhere
+        (`zero_grad(set_to_none=True)` followed by a backward, a `.grad` assigned by hand) is copied in first."""
+        for i, p in enumerate(self.params):
+            pv, gv = self.view(self.flat_param, i), self.view(self.flat_grad, i)
+            if p.data.data_ptr() != pv.data_ptr():
+                if p.data.device != self.flat_param.device:
+                    raise _lib.RnntHipError("a parameter moved to another device after the optimizer was built; build the "
+                                            "optimizer after model.to(device)")
+                pv.copy_(p.data)
+                p.data = pv
+            if p.grad is None:
+                gv.zero_()   # no gradient arrived since it was dropped: the slice must not keep an older step's values
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+                p.grad = gv
+            p._rnnt_direct_grad = self.direct_grads
+
+    def views_in_place(self) -> bool:
+        esz = self.flat_param.element_size()
+        p0, g0 = self.flat_param.data_ptr(), self.flat_grad.data_ptr()
+        return all(p.grad is not None and p.data_ptr() == p0 + off * esz and p.grad.data_ptr() == g0 + off * esz
+                   for p, off in zip(self.params, self.offsets))
+
+    def zero_grad(self) -> None:
+        if not self.views_in_place():
+            self.adopt()
+        self.flat_grad.zero_()
+
+    def all_reduce_grads(self) -> float:
+        """DDP semantics (train.py:45): SUM over ranks in ONE collective over the flat buffer; returns the 1/world factor
+        that turns the sum into DDP's average (FlatAdamW folds it into the update kernel; `average_grads` applies it here)."""
+        if self.world > 1:
+            if not self.views_in_place():
+                self.adopt()
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+        return 1.0 / self.world
+
+    def average_grads(self) -> None:
+        scale = self.all_reduce_grads()
+        if scale != 1.0:
+            self.flat_grad.mul_(scale)
+
+    def grad_bytes(self) -> int:
+        return self.flat_grad.numel() * self.flat_grad.element_size()
 
 
 class FlatAdamW(torch.optim.AdamW):
-    def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, direct_grads: bool = False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
-        if not ps:
-            raise ValueError("no trainable parameters")
-        dev = ps[0].device
-        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in ps):
-            raise _lib.RnntHipError("FlatAdamW needs all parameters in float32 on one GPU (move the module first)")
-        sizes = [(p.numel() + 3) // 4 * 4 for p in ps]  # keep every view 16-byte aligned
-        total = sum(sizes)
-        self.flat_param = torch.zeros(total, device=dev)
-        self.flat_grad = torch.zeros(total, device=dev)
-        self.flat_m = torch.zeros(total, device=dev)
-        self.flat_v = torch.zeros(total, device=dev)
-        off = 0
-        for p, n in zip(ps, sizes):
-            k = p.numel()
-            self.flat_param[off:off + k].copy_(p.data.reshape(-1))
-            p.data = self.flat_param[off:off + k].view_as(p)
-            p.grad = self.flat_grad[off:off + k].view_as(p)
-            self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.flat_m[off:off + k].view_as(p),
-                             "exp_avg_sq": self.flat_v[off:off + k].view_as(p)}
-            off += n
-        self._flat_params = ps
+        self.flat = FlatParams([p for g in self.param_groups for p in g["params"]], direct_grads=direct_grads)
+        self.flat_param, self.flat_grad = self.flat.flat_param, self.flat.flat_grad
+        self.flat_m = torch.zeros_like(self.flat_param)
+        self.flat_v = torch.zeros_like(self.flat_param)
         self._steps = 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._grad_scale = 1.0
+        self._point_state()
+        self.world = self.flat.world
+        self._status_host: Optional[torch.Tensor] = None   # pinned read-back slot of the device status word
+        self._status_event = None
 
-    def zero_grad(self, set_to_none: bool = False) -> None:  # keep the views: autograd accumulates in place
-        self.flat_grad.zero_()
+    # ---- state <-> flat moments ----------------------------------------------------------------------------------
+    def _point_state(self) -> None:
+        for i, p in enumerate(self.flat.params):
+            st = self.state[p]
+            if "step" not in st:
+                st["step"] = torch.tensor(float(self._steps))
+            st["exp_avg"] = self.flat.view(self.flat_m, i)
+            st["exp_avg_sq"] = self.flat.view(self.flat_v, i)
+
+    def load_state_dict(self, state_dict) -> None:
+        """torch's format in, flat buffers out: loaded moments are copied into flat_m / flat_v, `state[p]` is re-pointed at the
+        views and the step count (bias correction) is restored — a resumed run continues exactly where the saved one stopped."""
+        super().load_state_dict(state_dict)
+        steps = 0
+        for i, p in enumerate(self.flat.params):
+            st = self.state.get(p, {})
+            if "exp_avg" in st:
+                self.flat.view(self.flat_m, i).copy_(st["exp_avg"])
+                self.flat.view(self.flat_v, i).copy_(st["exp_avg_sq"])
+                steps = max(steps, int(float(st.get("step", 0))))
+            else:
+                self.flat.view(self.flat_m, i).zero_()
+                self.flat.view(self.flat_v, i).zero_()
+        self._steps = steps
+        for p in self.flat.params:
+            self.state[p]["step"] = torch.tensor(float(steps))
+        self._point_state()
+
+    # ---- gradients -----------------------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False) -> None:  # keep the views: autograd / the kernels accumulate in place
+        self.flat.zero_grad()
 
     def all_reduce_grads(self) -> None:
-        """DDP semantics (train.py:45): SUM over ranks, x 1/world — one collective over the flat buffer."""
-        if self.world > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-            self.flat_grad.mul_(1.0 / self.world)
+        """One RCCL all-reduce (SUM) over the flat gradient buffer; the 1/world of DDP's average rides in the next step()."""
+        self._grad_scale = self.flat.all_reduce_grads()
 
     def grad_bytes(self) -> int:
-        return self.flat_grad.numel() * 4
+        return self.flat.grad_bytes()
+
+    # ---- status word of the persistent recurrences ----------------------------------------------------------------
+    def _check_previous_status(self) -> None:
+        if self._status_event is None:
+            return
+        self._status_event.synchronize()  # recorded a whole step ago: already complete, costs nothing
+        self._status_event = None
+        if int(self._status_host[0]) != 0:
+            from .ops import lstm_status_word
+            lstm_status_word(self.flat_param.device).zero_()
+            raise _lib.RnntHipError("a persistent LSTM kernel of the previous step abandoned an inter-workgroup wait (4 s bound: "
+                                    "its workgroups were not co-resident — is another kernel holding the CUs?).  That step's "
+                                    "gradients were invalid; its AdamW update was skipped on device, parameters are intact.")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -63,15 +170,29 @@ class FlatAdamW(torch.optim.AdamW):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        g = self.param_groups[0]
         if len(self.param_groups) != 1:
             raise _lib.RnntHipError("FlatAdamW supports the reference's single parameter group (model.py:112)")
+        if not self.flat_param.is_cuda:
+            raise _lib.RnntHipError("FlatAdamW.step() runs on the MI355X only (rnnt_hip_adamw_step_ex); on CPU tensors this class "
+                                    "provides the flat buffers and the collective, not an update")
+        from .ops import _addr, _stream, lstm_status_word
+        self._check_previous_status()
+        if not self.flat.views_in_place():
+            self.flat.adopt()  # e.g. zero_grad(set_to_none=True) by an outer loop: gradients found elsewhere are copied in
+        g = self.param_groups[0]
         self._steps += 1
         b1, b2 = g["betas"]
-        _lib.check(_lib.lib().rnnt_hip_adamw_step(_addr(self.flat_param), _addr(self.flat_grad), _addr(self.flat_m),
-                                                  _addr(self.flat_v), self.flat_param.numel(), float(g["lr"]), float(b1),
-                                                  float(b2), float(g["eps"]), float(g["weight_decay"]), self._steps,
-                                                  _stream()), "rnnt_hip_adamw_step")
-        for p in self._flat_params:
+        status = lstm_status_word(self.flat_param.device)
+        _lib.check(_lib.lib().rnnt_hip_adamw_step_ex(_addr(self.flat_param), _addr(self.flat_grad), _addr(self.flat_m),
+                                                     _addr(self.flat_v), self.flat_param.numel(), float(g["lr"]), float(b1),
+                                                     float(b2), float(g["eps"]), float(g["weight_decay"]), self._steps,
+                                                     float(self._grad_scale), _addr(status), _stream()), "rnnt_hip_adamw_step_ex")
+        self._grad_scale = 1.0
+        if self._status_host is None:
+            self._status_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._status_host.copy_(status, non_blocking=True)
+        self._status_event = torch.cuda.Event()
+        self._status_event.record()
+        for p in self.flat.params:
             self.state[p]["step"] += 1
         return loss

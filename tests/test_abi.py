@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in rnnt_hip.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert _lib.lib().rnnt_hip_version() == 1
+    assert _lib.lib().rnnt_hip_version() == 2
 
 
 def test_argument_validation_happens_before_any_device_work():
@@ -68,10 +68,14 @@ def test_product_never_imports_the_oracle():
 
 
 def test_reference_style_checkpoint_round_trip(tmp_path):
-    """A Lightning-style .ckpt ({"state_dict": {"jointnet....": tensor}, ...}) written with the reference's key names loads
-    into the HIP module unchanged (SURVEY.md §8b parameter names/layouts)."""
+    """f-4: a Lightning .ckpt as the REFERENCE writes it — `state_dict` with its key names plus `hyper_parameters` holding what
+    `save_hyperparameters(prednet_params, transnet_params, jointnet_params, args)` stores at model.py:22 (three dicts and an
+    argparse.Namespace), epoch / global_step / optimizer_states — loads with a weights-only (no code execution) loader; and
+    what save_reference_checkpoint writes round-trips through the same loader and through from_reference_checkpoint
+    (inference.py:19-25)."""
     from rnntransducer_amd import RNNTransducer
-    args = Namespace(learning_rate=1e-3, weight_decay=1e-4, warmup_ratio=0.2, final_div_factor=1e4, total_steps=10)
+    args = Namespace(learning_rate=1e-3, weight_decay=1e-4, warmup_ratio=0.2, final_div_factor=1e4, total_steps=10, precision=32,
+                     val_on_cpu=False, vocab_path="config/vocab.json", move_metrics_to_cpu=False)
     cfg = (dict(embedding_size=10, hidden_size=8, output_size=8, num_layers=2), dict(input_size=12, hidden_size=8, output_size=8, num_layers=2),
            dict(num_classes=10))
     torch.manual_seed(1)
@@ -84,8 +88,27 @@ def test_reference_style_checkpoint_round_trip(tmp_path):
     for k, v in ref_like["decoder_rnn"].state_dict().items():
         assert sd["jointnet.decoder.rnn." + k].shape == v.shape
     path = tmp_path / "ref.ckpt"
-    torch.save({"state_dict": sd, "hyper_parameters": {"x": 1}, "epoch": 3}, path)
+    opt_ref = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(3))])
+    torch.save({"epoch": 3, "global_step": 1234, "pytorch-lightning_version": "1.8.0", "state_dict": sd,
+                "hyper_parameters": {"prednet_params": cfg[0], "transnet_params": cfg[1], "jointnet_params": cfg[2], "args": args},
+                "optimizer_states": [opt_ref.state_dict()], "lr_schedulers": [{"last_epoch": 1234}],
+                "callbacks": {}, "loops": {}}, path)
+    with pytest.raises(Exception):   # the plain weights-only loader refuses the Namespace: that was round 1's bug
+        torch.load(str(path), weights_only=True)
     b = RNNTransducer(*cfg, args)
     b.load_reference_checkpoint(str(path))
     for k, v in b.state_dict().items():
         assert torch.equal(v, sd[k]), k
+    blob = RNNTransducer.read_reference_checkpoint(str(path))
+    assert blob["hyper_parameters"]["args"].learning_rate == 1e-3 and blob["global_step"] == 1234
+    c = RNNTransducer.from_reference_checkpoint(str(path))          # ctor args from hyper_parameters
+    assert all(torch.equal(v, sd[k]) for k, v in c.state_dict().items())
+    # save side
+    out = tmp_path / "ours.ckpt"
+    b.save_reference_checkpoint(str(out), epoch=4, global_step=77)
+    blob2 = RNNTransducer.read_reference_checkpoint(str(out))
+    assert set(blob2["hyper_parameters"]) == {"prednet_params", "transnet_params", "jointnet_params", "args"}
+    assert isinstance(blob2["hyper_parameters"]["args"], Namespace) and blob2["epoch"] == 4 and blob2["global_step"] == 77
+    assert set(blob2["state_dict"]) == set(sd) and all(torch.equal(blob2["state_dict"][k], sd[k]) for k in sd)
+    d = RNNTransducer.from_reference_checkpoint(str(out))
+    assert all(torch.equal(v, sd[k]) for k, v in d.state_dict().items())

@@ -1,4 +1,5 @@
-"""N>1 path on CPU: world_size-2 gloo run of the flat-gradient all-reduce (rnntransducer_amd/dist.py) and the
+"""N>1 path on CPU: world_size-2 gloo run of the flat-gradient all-reduce — the SAME code bench.py and the product call
+(rnntransducer_amd/optim.py: FlatAdamW.all_reduce_grads -> FlatParams.all_reduce_grads, built here on CPU tensors) — and the
 length-grouped sharding (rnntransducer_amd/data.py), which mirror train.py:45 (DDP gradient averaging) and
 datasampler.py:74-99 (sort desc, wrap-pad, rank-strided deal)."""
 import os
@@ -9,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from rnntransducer_amd.data import length_grouped_indices, synthetic_batch
-from rnntransducer_amd.dist import FlatGradAllReduce
+from rnntransducer_amd.optim import FlatAdamW, FlatParams
 
 
 def _free_port():
@@ -25,14 +26,21 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
-    flat = FlatGradAllReduce(net.parameters())
+    opt = FlatAdamW(net.parameters(), lr=1e-3)  # the optimizer bench.py drives; only its step() kernel needs the GPU
+    assert opt.world == world and isinstance(opt.flat, FlatParams)
     data = torch.arange(world * 4 * 6, dtype=torch.float32).reshape(world * 4, 6) / 10.0
     shard = data[rank * 4:(rank + 1) * 4]
-    for _ in range(2):  # second iteration checks zero() really clears the views
-        flat.zero()
+    for it in range(3):  # later iterations check zero_grad() really clears the views ...
+        if it == 2:      # ... and that gradients which landed OUTSIDE the flat buffer (set_to_none loops) are re-adopted
+            for p in net.parameters():
+                p.grad = None
+        else:
+            opt.zero_grad()
         net(shard).pow(2).mean().backward()
-        flat.all_reduce()
-    out[rank] = flat.flat.clone()
+        opt.all_reduce_grads()                   # ONE collective over the flat buffer, SUM
+    assert opt.flat.views_in_place()
+    # x 1/world rides in the update kernel on the GPU; the .grad views skip the 16-byte alignment padding of the flat buffer
+    out[rank] = torch.cat([p.grad.flatten() for p in net.parameters()]) * opt._grad_scale
     dist.destroy_process_group()
 
 
