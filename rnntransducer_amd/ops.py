@@ -135,6 +135,9 @@ class LinearFn(torch.autograd.Function):
         W0 = _f32c(W, "weight")
         lead, K = x.shape[:-1], x.shape[-1]
         N = W.shape[0]
+        if W.dim() != 2 or W.shape[1] != K or (bias is not None and tuple(bias.shape) != (N,)):
+            raise ValueError(f"linear: x (..., {K}) needs weight (N, {K}) and bias (N,); got weight {tuple(W.shape)}, "
+                             f"bias {None if bias is None else tuple(bias.shape)}")
         M = x.numel() // K
         y = torch.empty(*lead, N, device=x.device, dtype=torch.float32)
         gemm(M, N, K, x, W0, y, bias=bias)
@@ -244,11 +247,26 @@ class LstmStackFn(torch.autograd.Function):
         if lens.dtype != torch.int32:
             raise ValueError(f"lengths must be int32 (dataloader.py:23-24), got {lens.dtype}")
         x = _f32c(x, "x")
-        params = weights
-        weights = [_f32c(w, "lstm weight") for w in weights]
+        if x.dim() != 3 or lens.shape != (x.shape[1],):
+            raise ValueError(f"x must be (T,B,I) with lens (B,): got {tuple(x.shape)} and {tuple(lens.shape)}")
         T, B, I0 = x.shape
         D = 2 if bidirectional else 1
         H = hidden
+        # the kernels index raw pointers: every weight's shape is checked here, on the host, before anything is launched
+        ngate = {0: 4, 1: 3, 2: 1, 3: 1}.get(cell)
+        if ngate is None or not isinstance(want_final, bool):
+            raise ValueError(f"cell must be 0..3 and want_final a bool (got cell={cell!r}, want_final={type(want_final).__name__})")
+        if len(weights) != 4 * D * num_layers:
+            raise ValueError(f"expected {4 * D * num_layers} weight tensors (w_ih, w_hh, b_ih, b_hh per layer and direction), got {len(weights)}")
+        for i, w in enumerate(weights):
+            layer, kind = i // (4 * D), i % 4
+            I_l = I0 if layer == 0 else D * H
+            want = [(ngate * H, I_l), (ngate * H, H), (ngate * H,), (ngate * H,)][kind]
+            if not isinstance(w, torch.Tensor) or tuple(w.shape) != want:
+                raise ValueError(f"lstm weight #{i} (layer {layer}, {['w_ih', 'w_hh', 'b_ih', 'b_hh'][kind]}): expected shape {want}, "
+                                 f"got {tuple(w.shape) if isinstance(w, torch.Tensor) else type(w).__name__}")
+        params = weights
+        weights = [_f32c(w, "lstm weight") for w in weights]
         dev = x.device
         ws = lstm_workspace(T, B, max(I0, D * H), H, D, dev)
         saved = []
@@ -509,6 +527,12 @@ def greedy_decode(enc_tm: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor, 
     L = len(rnn_weights) // 4
     if L > _lib.DECODE_MAX_LAYERS:
         raise ValueError(f"greedy decode supports at most {_lib.DECODE_MAX_LAYERS} prediction-net layers")
+    _check_prednet_weights(rnn_weights, cell, Hp)
+    if Od < 1 or tuple(out_w.shape) != (Od, Hp) or tuple(out_b.shape) != (Od,) or tuple(fc_b.shape) != (V,) or emb_w.shape[0] < 1:
+        raise ValueError(f"greedy decode: fc {tuple(fc_w.shape)} / out_proj {tuple(out_w.shape)} / embedding {tuple(emb_w.shape)} "
+                         f"do not fit encoder width {Oe}")
+    if not 0 <= blank < V or max_iters < 1:
+        raise ValueError(f"greedy decode: blank {blank} outside [0,{V}) or max_iters {max_iters} < 1")
     A = torch.empty(T, B, V, device=enc_tm.device, dtype=torch.float32)
     gemm(T * B, V, Oe, enc_tm, fc_w, A, b_sn=Ocat, b_sk=1, bias=fc_b, flags=GEMM_GELU_A)
     max_out = T * max_iters
@@ -530,6 +554,18 @@ def greedy_decode(enc_tm: torch.Tensor, fc_w: torch.Tensor, fc_b: torch.Tensor, 
     return tokens, ntok
 
 
+def _check_prednet_weights(rnn_weights, cell: int, H: int) -> None:
+    """Host-side shape check of a uni-directional prediction-net stack (input width == hidden width): the decode kernels
+    index raw pointers."""
+    ngate = {0: 4, 1: 3, 2: 1, 3: 1}.get(cell)
+    if ngate is None or len(rnn_weights) % 4 != 0 or not rnn_weights:
+        raise ValueError(f"prediction net: cell {cell!r} / {len(rnn_weights)} weight tensors")
+    for i, w in enumerate(rnn_weights):
+        want = [(ngate * H, H), (ngate * H, H), (ngate * H,), (ngate * H,)][i % 4]
+        if tuple(w.shape) != want:
+            raise ValueError(f"prediction-net weight #{i}: expected {want}, got {tuple(w.shape)}")
+
+
 def prednet_step(tokens: torch.Tensor, emb_w: torch.Tensor, rnn_weights, cell: int, h_in=None, c_in=None):
     """One prediction-net step for a batch with carried state (decoder.py:121-123).  tokens (B,) int64; h_in / c_in (L,B,H)
     or None (zeros) -> (h_out, c_out) with c_out None unless LSTM; the layer output is h_out[-1]."""
@@ -538,6 +574,10 @@ def prednet_step(tokens: torch.Tensor, emb_w: torch.Tensor, rnn_weights, cell: i
     B, H = tokens.numel(), emb_w.shape[1]
     if L > _lib.DECODE_MAX_LAYERS:
         raise ValueError(f"at most {_lib.DECODE_MAX_LAYERS} prediction-net layers")
+    _check_prednet_weights(rnn_weights, cell, H)
+    for name, t in (("h_in", h_in), ("c_in", c_in)):
+        if t is not None and tuple(t.shape) != (L, B, H):
+            raise ValueError(f"{name} must be (L,B,H) = ({L},{B},{H}), got {tuple(t.shape)}")
     tokens = tokens.reshape(-1).to(torch.int64).contiguous()
     h_out = torch.empty(L, B, H, device=emb_w.device, dtype=torch.float32)
     c_out = torch.empty_like(h_out) if cell == _lib.CELL_LSTM else None

@@ -95,7 +95,7 @@ def test_lstm_dropout_mask_is_consistent_between_fwd_and_bwd():
     w = hip.flat_weights()
 
     def run(xx):
-        return LstmStackFn.apply(xx, lens, 16, 2, True, 0.5, 1234, 0, *w)
+        return LstmStackFn.apply(xx, lens, 16, 2, True, 0.5, 1234, 0, False, *w)
 
     xr = x.clone().requires_grad_(True)
     proj = torch.randn(6, 3, 32, device="cuda")
@@ -108,6 +108,25 @@ def test_lstm_dropout_mask_is_consistent_between_fwd_and_bwd():
         fd = ((run(xp) * proj).sum() - (run(xm) * proj).sum()).item() / (2 * eps)
         assert abs(fd - xr.grad[idx].item()) < 2e-2 * max(1.0, abs(fd)), (idx, fd, xr.grad[idx].item())
     assert torch.equal(run(x), run(x))
+
+
+def test_lstm_stack_validates_weight_shapes_on_the_host():
+    """A wrong weight list must never reach the kernels (they index raw pointers): ValueError before any launch."""
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    from rnntransducer_amd.ops import LstmStackFn
+    hip = HipLSTM(8, 16, 2, dropout=0.0, bidirectional=True).cuda()
+    x = torch.randn(6, 3, 8, device="cuda")
+    lens = torch.tensor([6, 4, 2], dtype=torch.int32, device="cuda")
+    w = hip.flat_weights()
+    with pytest.raises(ValueError):
+        LstmStackFn.apply(x, lens, 16, 2, True, 0.0, 1, 0, False, *w[1:])            # one tensor short
+    with pytest.raises(ValueError):
+        LstmStackFn.apply(x, lens, 16, 2, True, 0.0, 1, 0, False, *(w[1:] + w[:1]))  # rotated: shapes do not match
+    with pytest.raises(ValueError):
+        LstmStackFn.apply(x, lens, 32, 2, True, 0.0, 1, 0, False, *w)                # wrong hidden size
+    with pytest.raises(ValueError):
+        LstmStackFn.apply(x, lens[:2], 16, 2, True, 0.0, 1, 0, False, *w)            # lens does not cover the batch
+    torch.cuda.synchronize()
 
 
 def test_lstm_rejects_unsupported():
