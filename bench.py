@@ -138,12 +138,29 @@ def parity_vs_float64_oracle(model, tn, pn, V, batch, nb, threads):
     cpu_sub = tuple((x.cpu() if isinstance(x, torch.Tensor) else x) for x in sub)
     ref = training_loss(oracle, (cpu_sub[0].double(),) + cpu_sub[1:])
     ref.backward()
+    ref_loss = float(ref.detach())
     ref_grads = {k: p.grad for k, p in oracle.named_parameters() if k in GRAD_PROBES}
-    devs = {k: {"max_abs_dev": float((hip_grads[k] - ref_grads[k]).abs().max()), "ref_max_abs": float(ref_grads[k].abs().max())}
-            for k in GRAD_PROBES}
-    for v in devs.values():
-        v["rel_to_max"] = v["max_abs_dev"] / max(v["ref_max_abs"], 1e-30)
-    return abs(hip_loss - float(ref)) / abs(float(ref)), devs
+    # the same sample through the fp32 oracle (torch-CPU fp32 = the REFERENCE's own arithmetic): how far plain fp32 sits
+    # from float64 on these gradients is the yardstick for the HIP path's distance (sums with heavy cancellation:
+    # tools/parity_probe.py shows the distance does not move with exact cell math or f32-input MFMA)
+    o32 = _oracle_for(model, tn, pn, V, double=False)
+    l32 = training_loss(o32, cpu_sub)
+    l32.backward()
+    f32_grads = {k: p.grad.double() for k, p in o32.named_parameters() if k in GRAD_PROBES}
+    devs = {}
+    for k in GRAD_PROBES:
+        scale = float(ref_grads[k].abs().max())
+        devs[k] = {"max_abs_dev": float((hip_grads[k] - ref_grads[k]).abs().max()), "ref_max_abs": scale,
+                   "fp32_oracle_max_abs_dev": float((f32_grads[k] - ref_grads[k]).abs().max())}
+        devs[k]["rel_to_max"] = devs[k]["max_abs_dev"] / max(scale, 1e-30)
+        devs[k]["fp32_oracle_rel_to_max"] = devs[k]["fp32_oracle_max_abs_dev"] / max(scale, 1e-30)
+    return abs(hip_loss - ref_loss) / abs(ref_loss), devs, abs(float(l32.detach()) - ref_loss) / abs(ref_loss)
+
+
+def grad_within_tolerance(v):
+    """max_abs_dev <= 2e-4 * max(|ref|max, 1e-3) (the bound tests/test_gpu_model.py uses at initial weights), or — on
+    weights where plain fp32 itself is further than that from float64 — within 1.5x of the fp32 oracle's own deviation."""
+    return v["max_abs_dev"] <= max(2e-4 * max(v["ref_max_abs"], 1e-3), 1.5 * v["fp32_oracle_max_abs_dev"])
 
 
 def main():
@@ -308,10 +325,13 @@ def main():
         threads = a.cpu_threads or cores
         # (1) parity: HIP (dropout off, CURRENT weights — they moved during the timed steps) vs the FLOAT64 oracle
         npar = min(a.parity_sample, B)
-        out["loss_rel_delta"], out["grad_max_abs_dev"] = parity_vs_float64_oracle(model, tn, pn, V, batch, npar, threads)
-        out["parity"] = {"oracle": f"float64 CPU oracle, first {npar} utterances of the bench batch, dropout off",
-                         "loss_rel_tol": 1e-4, "grad_tol": "max_abs_dev <= 2e-4 * max(ref_max_abs, 1e-3) (the bound tests/test_gpu_model.py uses)"}
-        parity_ok = out["loss_rel_delta"] <= 1e-4 and all(v["max_abs_dev"] <= 2e-4 * max(v["ref_max_abs"], 1e-3) for v in out["grad_max_abs_dev"].values())
+        out["loss_rel_delta"], out["grad_max_abs_dev"], f32_loss_rel = parity_vs_float64_oracle(model, tn, pn, V, batch, npar, threads)
+        out["parity"] = {"oracle": f"float64 CPU oracle, first {npar} utterances of the bench batch, dropout off, weights after "
+                                   f"{a.warmup + a.steps} AdamW steps",
+                         "loss_rel_tol": 1e-4, "fp32_oracle_loss_rel_delta": f32_loss_rel,
+                         "grad_tol": "max_abs_dev <= max(2e-4 * max(ref_max_abs, 1e-3), 1.5 * fp32_oracle_max_abs_dev): within the "
+                                     "fixture tests' bound, or as close to float64 as the reference's own fp32 arithmetic (torch CPU)"}
+        parity_ok = out["loss_rel_delta"] <= 1e-4 and all(grad_within_tolerance(v) for v in out["grad_max_abs_dev"].values())
         out["parity"]["ok"] = parity_ok
         # (2) reported CPU baseline: fp32 oracle, 1 warm-up + 3 timed full train steps, median
         nb = min(a.cpu_sample, B)
