@@ -104,6 +104,28 @@ size_t rnnt_hip_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * fp32 GEMM on the f16 matrix cores through "half-pair" (hp) operands — the form the BIG products of the hot path use
+ * inside rnnt_hip_lstm_fwd / _bwd (hoisted input projection of nn.LSTM, networks/encoder.py:67-75,99, and its backward
+ * products dX, dW_ih, dW_hh): 3 instead of 6 MFMA products per fp32 product, operands streamed to LDS by LDS-DMA.
+ *
+ * hp planes of an fp32 tensor x (rows x K): amax = max|x| (a device word the split writes, or the caller supplies),
+ *   v = x * 2^(14 - floor(log2 amax)),  hi = fp16_rn(v),  lo = fp16_rn(v - hi)   (v = hi + lo to 2^-23 |v|, 2^-40 amax floor)
+ *   layout: row-major, K padded to 32, one 128-byte line per (row, 32-k block): 32 hi | 32 lo.  rnnt_hip_hp_bytes(rows, K).
+ * rnnt_hip_hp_split: transpose == 0: x is (rows x K), row stride ld.  transpose == 1: x is (src_rows x >= rows), row stride
+ *   ld; plane row r, index k holds x[k + shift][r] (0 outside [0, src_rows)) — the transposed operands of the weight-gradient
+ *   products, time-shifted for dW_hh.  amax_given == 0: the split first computes amax over the source view.
+ * rnnt_hip_gemm_hp: C (M x N, row stride ldc) [+]= A (M x K) . B (N x K)^T + bias, both operands hp planes (NT form), fp32 out.
+ *   flags: RNNT_GEMM_ACCUM.  workspace (optional, rnnt_hip_gemm_hp_workspace_bytes): deterministic split-K slabs.
+ * ---------------------------------------------------------------------------------------------- */
+size_t rnnt_hip_hp_bytes(int64_t rows, int64_t K);
+int rnnt_hip_hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, int32_t transpose, int64_t src_rows, int64_t shift,
+                      void* planes, uint32_t* amax, int32_t amax_given, void* stream);
+size_t rnnt_hip_gemm_hp_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int rnnt_hip_gemm_hp(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N, int64_t K,
+                     float* C, int64_t ldc, const float* bias, uint32_t flags, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LSTM layer (both directions in one launch), packed-sequence semantics.
  * Replaces torch.nn.LSTM over a PackedSequence + sort/pack/unpack/unsort:
  *   networks/encoder.py:67-75 (ctor), :93-102 (forward);  networks/decoder.py:71-79, :105-120.

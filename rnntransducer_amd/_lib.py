@@ -69,6 +69,11 @@ SYMBOLS = {
     "rnnt_hip_prof_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "rnnt_hip_gemm_workspace_bytes": (C.c_size_t, [c_i64, c_i64, c_i64]),
     "rnnt_hip_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "rnnt_hip_hp_bytes": (C.c_size_t, [c_i64, c_i64]),
+    "rnnt_hip_hp_split": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_i32, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i32, C.c_void_p]),
+    "rnnt_hip_gemm_hp_workspace_bytes": (C.c_size_t, [c_i64, c_i64, c_i64]),
+    "rnnt_hip_gemm_hp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, c_i64, C.c_void_p,
+                                  C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_lstm_workspace_bytes": (C.c_size_t, [c_i32] * 5),
     "rnnt_hip_lstm_max_batch": (c_i32, [c_i32, c_i32, c_i32]),
     "rnnt_hip_lstm_fwd": (C.c_int, [C.POINTER(LstmDesc), C.c_void_p]),

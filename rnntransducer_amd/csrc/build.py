@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 INCLUDE = os.path.join(ROOT, "include")
-SOURCES = ["api.hip", "gemm.hip", "loss.hip", "lstm.hip", "decode.hip", "frontend.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_hp.hip", "loss.hip", "lstm.hip", "decode.hip", "frontend.hip"]
 LIB = os.path.join(HERE, "librnnt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + HERE, "-Wno-unused-result"]

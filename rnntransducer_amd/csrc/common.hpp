@@ -42,6 +42,17 @@ struct ProfScope {
 };
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// half-pair (hp) operands and the f16-MFMA GEMM on them (gemm_hp.hip); used by lstm.hip for its big products
+size_t hp_plane_bytes(int64_t rows, int64_t K);
+int hp_amax(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, hipStream_t s);
+int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, const uint32_t* amax, void* planes, hipStream_t s);
+int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, int64_t shift, const uint32_t* amax, void* planes,
+               hipStream_t s);
+size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N, int64_t K, float* C,
+            int64_t c_div, int64_t c_so, int64_t c_si, const float* bias, unsigned flags, void* workspace, size_t workspace_bytes,
+            hipStream_t s);
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // gelu_tanh and its derivative (torch.nn.GELU(approximate="tanh"), networks/transducer.py:38)

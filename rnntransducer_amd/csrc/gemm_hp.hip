@@ -1,0 +1,448 @@
+// fp32 GEMM on the f16 matrix cores of gfx950 through "half-pair" (hp) operands: three v_mfma_f32_16x16x32_f16 per fp32
+// product block instead of six bf16 ones (gemm.hip), operands delivered to LDS by LDS-DMA with no VALU in the main loop.
+//
+// Replaces the BLAS calls behind the BIG products of the hot path: the hoisted LSTM input projection W_ih.x_t over all
+// frames (networks/encoder.py:67-75,99) and its three backward products dX = dG.W_ih, dW_ih = dG^T.X, dW_hh = dG^T.h_prev
+// (autograd of the same lines) — 95 % of the step's GEMM FLOPs at BASELINE configs[1].  Small / oddly shaped products
+// (out_proj, joint pre-GEMMs, K < 256) stay on gemm.hip.
+//
+// hp format of an fp32 tensor x (rows x K) with amax = max|x|:  s = 2^(14 - floor(log2 amax)), v = x * s  (|v| < 2^15),
+//   hi = fp16_rn(v),  lo = fp16_rn(v - hi)   =>   v = hi + lo + e,  |e| <= 2^-23 |v|   (11 + 1 + 11 significant bits)
+//   stored row-major, K padded to 32, per (row, 32-k block) ONE 128-byte line: 32 x hi | 32 x lo.
+// Values more than 2^17 below amax lose relative (not absolute) precision: |e| <= 2^-40 amax — below the fp32 rounding of
+// any sum the large elements take part in.  a.b ~= s_a^-1 s_b^-1 (a_lo b_hi + a_hi b_lo + a_hi b_hi): the dropped a_lo b_lo is
+// <= 2^-22 |a b|, typically 2^-25; products and sums are exact / fp32-accumulated in the MFMA.  Measured against fp64:
+// tests/test_gpu_gemm.py::test_gemm_hp_*.
+//
+// Kernel (NT form only: both operands k-contiguous; transposed operands are produced as such by the split kernels):
+//   256 x 256 x 32 tile, 512 threads = 8 waves as 2 (M) x 4 (N), 128 x 64 of C per wave = 8 x 4 blocks of 16 x 16,
+//   96 MFMAs per wave per K-tile; 2 x 64 KB LDS stages filled by buffer_load_dwordx4 ... lds (8 per thread per K-tile),
+//   LDS rows of 128 B (hi | lo) with the 16-byte slot s of row r stored at slot s ^ ((r >> 1) & 7): every ds_read_b128 of a
+//   16x16x32 operand fragment is bank-conflict-free; the swizzle is applied on the per-lane SOURCE address (LDS-DMA writes
+//   lane-linear).
+#include "common.hpp"
+
+#include <stdlib.h>
+
+namespace rnnt {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int HP_BM = 256, HP_BN = 256, HP_BK = 32;
+constexpr int HP_STAGE = (HP_BM + HP_BN) * 128;  // bytes per K-tile stage (A rows | B rows, 128 B each)
+constexpr int HP_RSRC = 0x00027000;
+
+__device__ __forceinline__ float hp_scale_from_amax(unsigned amax_bits) {
+  // 2^(14 - e) with e = floor(log2 amax); amax == 0 (or denormal) -> 1
+  int eb = (int)((amax_bits >> 23) & 255u);
+  if (eb == 0) return 1.0f;
+  eb = eb < 15 ? 15 : eb;  // |x| < 2^-112 everywhere: keep both factors finite (scale * inv_scale == 1 exactly either way)
+  return __uint_as_float((unsigned)(268 - eb) << 23);
+}
+__device__ __forceinline__ float hp_inv_scale_from_amax(unsigned amax_bits) {
+  int eb = (int)((amax_bits >> 23) & 255u);
+  if (eb == 0) return 1.0f;
+  eb = eb < 15 ? 15 : eb;
+  return __uint_as_float((unsigned)(eb - 14) << 23);  // 2^(e - 14), e = eb - 127
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// amax: max |x| over a (rows x K) view with row stride ld, as the bit pattern of the non-negative float (atomicMax on
+// unsigned orders them like the floats)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) hp_amax_kernel(const float* __restrict__ x, long rows, int K, long ld, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const long total = rows * (long)K;
+  if (ld == K && (K & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const long n4 = total >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+      m = max(max(m, v[0] & 0x7fffffffu), max(max(v[1] & 0x7fffffffu, v[2] & 0x7fffffffu), v[3] & 0x7fffffffu));
+    }
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+      m = max(m, __float_as_uint(x[(i / K) * ld + (i % K)]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(out, m);
+}
+
+__device__ __forceinline__ void hp_split8(const float (&x)[8], float scale, u32x4& hi, u32x4& lo) {
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = x[e] * scale;
+    const _Float16 a = (_Float16)v;   // round to nearest even
+    h[e] = a;
+    l[e] = (_Float16)(v - (float)a);  // exact residual, rounded once
+  }
+  hi = __builtin_bit_cast(u32x4, h);
+  lo = __builtin_bit_cast(u32x4, l);
+}
+
+// x (rows x K, row stride ld) -> planes[rows][Kp/32][hi 32 | lo 32]; one thread per (row, 8-k chunk)
+__global__ void __launch_bounds__(256) hp_split_kernel(const float* __restrict__ x, long rows, int K, long ld, const unsigned* __restrict__ amax,
+                                                       char* __restrict__ out) {
+  const int Kp = (K + 31) & ~31, cpr = Kp >> 3;
+  const long total = rows * cpr;
+  const float scale = hp_scale_from_amax(*amax);
+  const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cpr;
+    const int c = (int)(i % cpr), k = 8 * c;
+    const float* src = x + r * ld + k;
+    float v[8];
+    if (vec && k + 7 < K) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? src[e] : 0.f;
+    }
+    u32x4 hi, lo;
+    hp_split8(v, scale, hi, lo);
+    char* dst = out + (r * (Kp >> 5) + (c >> 2)) * 128 + 16 * (c & 3);
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + 64) = lo;
+  }
+}
+
+// transposed: x is (Ksrc rows x >= R cols, row stride ld); planes row r (= source column c0 + r), contraction index k in [0, K):
+// value x[k + shift][c0 + r] (0 when k + shift is outside [0, Ksrc)).  Workgroup = 32 k x 256 source columns through LDS.
+__global__ void __launch_bounds__(256) hp_split_t_kernel(const float* __restrict__ x, int R, int K, long ld, int Ksrc, int shift,
+                                                         const unsigned* __restrict__ amax, char* __restrict__ out) {
+  __shared__ float tile[32][257];
+  const int kb = blockIdx.x, r0 = blockIdx.y * 256;
+  const int tid = threadIdx.x;
+  const float scale = hp_scale_from_amax(*amax);
+  // load: pass q covers source rows 4q..4q+3, each row 64 threads x 4 columns
+  const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int kk = 4 * q + (tid >> 6);
+    const int ksrc = kb * 32 + kk + shift;
+    const int c = 4 * (tid & 63);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kb * 32 + kk < K && ksrc >= 0 && ksrc < Ksrc) {
+      const float* src = x + (long)ksrc * ld + r0 + c;
+      if (vec && r0 + c + 3 < R) {
+        v = *reinterpret_cast<const f32x4*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (r0 + c + e < R) v[e] = src[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[kk][c + e] = v[e];
+  }
+  __syncthreads();
+  // store: thread -> (output row r0 + tid/4 + 64*pass, chunk tid%4)
+  const int Kp32 = (K + 31) >> 5;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int rl = (tid >> 2) + 64 * ps, ch = tid & 3;
+    if (r0 + rl < R) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[8 * ch + e][rl];
+      u32x4 hi, lo;
+      hp_split8(v, scale, hi, lo);
+      char* dst = out + ((long)(r0 + rl) * Kp32 + kb) * 128 + 16 * ch;
+      *reinterpret_cast<u32x4*>(dst) = hi;
+      *reinterpret_cast<u32x4*>(dst + 64) = lo;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+struct HpGemmK {
+  int M, N, nkt;             // nkt = K-tiles (32 k each) of the whole contraction
+  const char* A; unsigned a_pitch, a_bytes;   // hp planes, bytes per row = nkt * 128
+  const char* B; unsigned b_pitch, b_bytes;
+  const unsigned* a_amax; const unsigned* b_amax;
+  float* C; int c_div; long c_so, c_si;
+  const float* bias;
+  unsigned flags;            // RNNT_GEMM_ACCUM
+  int splits, kt_per_split;  // blockIdx.y = split z handles K-tiles [z * kt_per_split, ...)
+  float* slab;               // splits > 1: slab[z][M][N]
+  int tiles_m, tiles_n;
+};
+
+// same bijective XCD remap idea as gemm.hip: consecutive tiles of one XCD share operand panels through its L2
+__device__ __forceinline__ int hp_xcd_remap(int bid, int n) {
+  const int q = n / 8, r = n % 8, xcd = bid % 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+__global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int bid = hp_xcd_remap(blockIdx.x, ntiles);
+  const int m0 = (bid % p.tiles_m) * HP_BM, n0 = (bid / p.tiles_m) * HP_BN;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, (int)p.a_bytes, HP_RSRC);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, (int)p.b_bytes, HP_RSRC);
+
+  // LDS-DMA piece j of this wave: tile rows (8j + wave) * 8 .. + 7, lane -> (row lane>>3, LDS slot lane&7), which holds source
+  // slot (lane&7) ^ ((row >> 1) & 7) = (lane&7) ^ (((lane >> 4) & 3) | ((wave & 1) << 2))
+  unsigned va[4], vb[4];
+  {
+    const int src_slot = (lane & 7) ^ (((lane >> 4) & 3) | ((wave & 1) << 2));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (8 * j + wave) * 8 + (lane >> 3);
+      const int ma = min(m0 + row, p.M - 1), nb = min(n0 + row, p.N - 1);  // rows past the edge re-read the last row (never stored)
+      va[j] = (unsigned)ma * p.a_pitch + 16u * src_slot;
+      vb[j] = (unsigned)nb * p.b_pitch + 16u * src_slot;
+    }
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = lds + buf * HP_STAGE;
+    const int koff = kt * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (8 * j + wave) * 1024), 16, va[j], koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + HP_BM * 128 + (8 * j + wave) * 1024), 16, vb[j], koff, 0, 0);
+    }
+  };
+
+  // operand fragment of a 16-row block: lane -> row lane&15, k 8*(lane>>4)..+7 of plane pl: slot (4 pl + (lane>>4)) ^ ((row>>1)&7)
+  const int frag0 = (lane & 15) * 128 + 16 * ((lane >> 4) ^ ((lane & 15) >> 1));   // plane hi; plane lo = frag0 ^ 64
+  const int a_base = wr * (128 * 128) + frag0;
+  const int b_base = HP_BM * 128 + wc * (64 * 128) + frag0;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int kt0 = blockIdx.y * p.kt_per_split;
+  const int nk = min(p.nkt - kt0, p.kt_per_split);
+
+  stage(0, kt0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt0 + kt + 1);   // lands under this tile's 96 MFMAs
+    const char* sb = lds + cur * HP_STAGE;
+    f16x8 a[4][2], b[2][2];
+    auto load_a = [&](int mq) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i][0] = *reinterpret_cast<const f16x8*>(sb + (a_base + (4 * mq + i) * 2048));
+        a[i][1] = *reinterpret_cast<const f16x8*>(sb + ((a_base ^ 64) + (4 * mq + i) * 2048));
+      }
+    };
+    auto load_b = [&](int nq) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        b[j][0] = *reinterpret_cast<const f16x8*>(sb + (b_base + (2 * nq + j) * 2048));
+        b[j][1] = *reinterpret_cast<const f16x8*>(sb + ((b_base ^ 64) + (2 * nq + j) * 2048));
+      }
+    };
+    auto mma = [&](int mq, int nq) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 c = acc[4 * mq + i][2 * nq + j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], b[j][0], c, 0, 0, 0);  // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[4 * mq + i][2 * nq + j] = c;
+        }
+    };
+    load_a(0); load_b(0); mma(0, 0);
+    load_b(1); mma(0, 1);
+    load_a(1); mma(1, 1);
+    load_b(0); mma(1, 0);
+    __builtin_amdgcn_sched_barrier(0);  // keep all 96 MFMAs in front of the wait (hipcc otherwise sinks half of them behind the barrier)
+    __syncthreads();   // drains the LDS-DMA of the next stage (vmcnt(0)) and fences this stage's reads
+  }
+
+  // epilogue: D block (i, j): lane -> rows 4*(lane>>4) + reg, column lane&15
+  const float scale = hp_inv_scale_from_amax(*p.a_amax) * hp_inv_scale_from_amax(*p.b_amax);
+  const int mode = p.splits > 1 ? 0 : ((p.flags & RNNT_GEMM_ACCUM) ? 2 : 1);  // uniform: slab | store | accumulate
+  float* slab = p.splits > 1 ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
+  float bias_v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+    bias_v[j] = (mode != 0 && p.bias && n < p.N) ? p.bias[n] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = m0 + wr * 128 + i * 16 + 4 * (lane >> 4) + reg;
+      const bool mok = m < p.M;
+      const int mc = mok ? m : 0;
+      float* crow = mode == 0 ? slab + (long)mc * p.N : p.C + (long)(mc / p.c_div) * p.c_so + (long)(mc % p.c_div) * p.c_si;
+      float old[4] = {0.f, 0.f, 0.f, 0.f};
+      if (mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+          if (mok && n < p.N) old[j] = crow[n];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+        if (mok && n < p.N) crow[n] = acc[i][j][reg] * scale + bias_v[j] + old[j];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) hp_splitk_reduce_kernel(const HpGemmK p) {
+  const long total = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float s = 0.f;
+    for (int z = 0; z < p.splits; ++z) s += p.slab[(long)z * total + i];
+    if (p.bias) s += p.bias[n];
+    const long off = (long)(m / p.c_div) * p.c_so + (long)(m % p.c_div) * p.c_si + n;
+    if (p.flags & RNNT_GEMM_ACCUM) s += p.C[off];
+    p.C[off] = s;
+  }
+}
+
+}  // namespace
+
+// internal entry points shared with lstm.hip -------------------------------------------------------------------------
+size_t hp_plane_bytes(int64_t rows, int64_t K) { return (size_t)rows * (size_t)ceil_div(K, 32) * 128; }
+
+int hp_amax(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, hipStream_t s) {
+  RNNT_CHECK_HIP(hipMemsetAsync(amax, 0, 4, s));
+  const long total = rows * K;
+  if (total == 0) return RNNT_OK;
+  const long blocks = ceil_div(ceil_div(total, 4), 256);
+  ProfScope prof(RNNT_K_MISC, 4.0 * (double)total, s);
+  hipLaunchKernelGGL(hp_amax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, x, (long)rows, (int)K, (long)ld, amax);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, const uint32_t* amax, void* planes, hipStream_t s) {
+  if (rows == 0) return RNNT_OK;
+  const long total = rows * ceil_div(K, 32) * 4;
+  const long blocks = ceil_div(total, 256);
+  ProfScope prof(RNNT_K_MISC, 8.0 * (double)rows * (double)K, s);
+  hipLaunchKernelGGL(hp_split_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, x, (long)rows, (int)K, (long)ld, amax,
+                     (char*)planes);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, int64_t shift, const uint32_t* amax, void* planes,
+               hipStream_t s) {
+  if (R == 0 || K == 0) return RNNT_OK;
+  ProfScope prof(RNNT_K_MISC, 8.0 * (double)R * (double)K, s);
+  hipLaunchKernelGGL(hp_split_t_kernel, dim3((unsigned)ceil_div(K, 32), (unsigned)ceil_div(R, 256)), dim3(256), 0, s, x, (int)R, (int)K, (long)ld,
+                     (int)Ksrc, (int)shift, amax, (char*)planes);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
+size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const long tiles = ceil_div(M, HP_BM) * ceil_div(N, HP_BN);
+  const long nkt = ceil_div(K, HP_BK);
+  if (tiles >= 192 || nkt < 64) return 0;
+  long want = ceil_div(256, tiles);
+  if (want > nkt / 32) want = nkt / 32;
+  if (want > 32) want = 32;
+  return want >= 2 ? (size_t)want * M * N * 4 : 0;
+}
+
+int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N, int64_t K, float* C,
+            int64_t c_div, int64_t c_so, int64_t c_si, const float* bias, unsigned flags, void* workspace, size_t workspace_bytes,
+            hipStream_t s) {
+  RNNT_CHECK_ARG(A && B && C && a_amax && b_amax, "gemm_hp: null operand");
+  RNNT_CHECK_ARG(M >= 1 && N >= 1 && K >= 1 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm_hp: bad dims");
+  RNNT_CHECK_ARG(c_div >= 1, "gemm_hp: c_div must be >= 1");
+  RNNT_CHECK_ARG(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 127) == 0, "gemm_hp: planes must be 128-byte aligned");
+  HpGemmK k;
+  k.M = (int)M; k.N = (int)N; k.nkt = (int)ceil_div(K, HP_BK);
+  const size_t ab = hp_plane_bytes(M, K), bb = hp_plane_bytes(N, K);
+  RNNT_CHECK_ARG(ab < (1ull << 32) && bb < (1ull << 32), "gemm_hp: an operand exceeds the 4 GB a buffer resource addresses");
+  k.A = (const char*)A; k.a_pitch = (unsigned)k.nkt * 128u; k.a_bytes = (unsigned)ab;
+  k.B = (const char*)B; k.b_pitch = (unsigned)k.nkt * 128u; k.b_bytes = (unsigned)bb;
+  k.a_amax = a_amax; k.b_amax = b_amax;
+  k.C = C; k.c_div = (int)(c_div > 0x7fffffff ? 0x7fffffff : c_div); k.c_so = c_so; k.c_si = c_si;
+  k.bias = bias; k.flags = flags;
+  k.tiles_m = (int)ceil_div(M, HP_BM); k.tiles_n = (int)ceil_div(N, HP_BN);
+  const int tiles = k.tiles_m * k.tiles_n;
+  int splits = 1;
+  if (workspace && tiles < 192 && k.nkt >= 64) {  // too few tiles for 256 CUs and a deep contraction (weight gradients): split K
+    long want = ceil_div(256, tiles);
+    const long by_ws = (long)(workspace_bytes / ((size_t)M * N * 4));
+    if (want > k.nkt / 32) want = k.nkt / 32;
+    if (want > by_ws) want = by_ws;
+    if (want > 32) want = 32;
+    if (want >= 2) splits = (int)want;
+  }
+  k.kt_per_split = (int)ceil_div(k.nkt, splits);
+  splits = (int)ceil_div(k.nkt, k.kt_per_split);
+  k.splits = splits;
+  k.slab = (float*)workspace;
+  RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HP_STAGE));
+  {
+    ProfScope prof(RNNT_K_GEMM, 2.0 * (double)M * (double)N * (double)K, s);
+    hipLaunchKernelGGL(gemm_hp_kernel, dim3(tiles, splits), dim3(512), 2 * HP_STAGE, s, k);
+    RNNT_CHECK_LAUNCH();
+    if (splits > 1) {
+      const long blocks = ceil_div((long)M * N, 256);
+      hipLaunchKernelGGL(hp_splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, k);
+      RNNT_CHECK_LAUNCH();
+    }
+  }
+  return RNNT_OK;
+}
+
+}  // namespace rnnt
+
+using namespace rnnt;
+
+extern "C" size_t rnnt_hip_hp_bytes(int64_t rows, int64_t K) {
+  if (rows < 0 || K < 0) return 0;
+  return hp_plane_bytes(rows, K);
+}
+
+extern "C" int rnnt_hip_hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, int32_t transpose, int64_t src_rows, int64_t shift,
+                                 void* planes, uint32_t* amax, int32_t amax_given, void* stream) {
+  RNNT_CHECK_ARG(x && planes && amax && rows >= 0 && K >= 0, "hp_split: bad arguments");
+  RNNT_CHECK_ARG((reinterpret_cast<uintptr_t>(planes) & 127) == 0, "hp_split: planes must be 128-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (!transpose) {
+    RNNT_CHECK_ARG(ld >= K, "hp_split: ld < K");
+    if (!amax_given)
+      if (int rc = hp_amax(x, rows, K, ld, amax, s)) return rc;
+    return hp_split(x, rows, K, ld, amax, planes, s);
+  }
+  RNNT_CHECK_ARG(ld >= rows && src_rows >= 1, "hp_split: transposed source is (src_rows x >= rows), ld >= rows");
+  if (!amax_given)
+    if (int rc = hp_amax(x, src_rows, rows, ld, amax, s)) return rc;
+  return hp_split_t(x, rows, K, ld, src_rows, shift, amax, planes, s);
+}
+
+extern "C" size_t rnnt_hip_gemm_hp_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || N < 1 || K < 1) return 0;
+  return hp_gemm_workspace_bytes(M, N, K);
+}
+
+extern "C" int rnnt_hip_gemm_hp(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N,
+                                int64_t K, float* C, int64_t ldc, const float* bias, uint32_t flags, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  RNNT_CHECK_ARG(ldc >= N, "gemm_hp: ldc < N");
+  return hp_gemm(A, a_amax, B, b_amax, M, N, K, C, 1, ldc, 0, bias, flags, workspace, workspace_bytes, (hipStream_t)stream);
+}

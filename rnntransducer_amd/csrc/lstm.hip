@@ -1525,8 +1525,23 @@ struct LstmWs {
   size_t dbp_half;  // floats per side
   void* scratch;  // split-K slabs of the weight-gradient GEMMs / column-sum partials
   size_t scratch_bytes;
+  // half-pair operand planes of the big products (gemm_hp.hip); null when the shape stays on gemm.hip
+  bool hp;
+  char* hp_x;    // fwd: x (T*B, I)            bwd: x^T (I, T*B)
+  char* hp_w;    // fwd: W_ih' (D*4H, I)       bwd: W_ih'^T (I, D*4H)
+  char* hp_dg;   // bwd: dG (T*B, D*4H)
+  char* hp_dgt;  // bwd: dG^T (D*4H, T*B)
+  char* hp_yt;   // bwd: time-shifted h^T per direction (D, H, T*B)
+  uint32_t* hp_amax;  // 8 device words
   size_t total;
 };
+
+// the hp path pays for the big products only (the operand conversion passes are fixed costs)
+inline bool use_hp(int T, int B, int I, int H, int D) {
+  if (getenv("RNNT_GEMM_NO_HP")) return false;
+  const long M = (long)T * B, N4 = (long)D * 4 * H;
+  return M >= 1024 && N4 >= 512 && H >= 128 && (getenv("RNNT_GEMM_FORCE_HP") || (M * N4 >= (1l << 22)));
+}
 
 struct Plan {
   int Hs, NC, MT, NT, Bp, LDW, wgs_per_cu;
@@ -1671,8 +1686,24 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
     const size_t s3 = rnnt_hip_colsum_workspace_bytes(M, N4);
     if (s2 > sc) sc = s2;
     if (s3 > sc) sc = s3;
+    w.hp = use_hp(T, B, I, H, D);
+    if (w.hp) {
+      const size_t h1 = hp_gemm_workspace_bytes(N4, I, M), h2 = hp_gemm_workspace_bytes(4 * H, H, M);
+      if (h1 > sc) sc = h1;
+      if (h2 > sc) sc = h2;
+    }
     w.scratch_bytes = sc;
     w.scratch = take(sc);
+    w.hp_x = w.hp_w = w.hp_dg = w.hp_dgt = w.hp_yt = nullptr;
+    w.hp_amax = nullptr;
+    if (w.hp) {
+      w.hp_amax = reinterpret_cast<uint32_t*>(take(256));
+      w.hp_x = take(hp_plane_bytes(M, I) > hp_plane_bytes(I, M) ? hp_plane_bytes(M, I) : hp_plane_bytes(I, M));
+      w.hp_w = take(hp_plane_bytes(N4, I) > hp_plane_bytes(I, N4) ? hp_plane_bytes(N4, I) : hp_plane_bytes(I, N4));
+      w.hp_dg = take(hp_plane_bytes(M, N4));
+      w.hp_dgt = take(hp_plane_bytes(N4, M));
+      w.hp_yt = take((size_t)D * hp_plane_bytes(H, M));
+    }
   }
   w.total = off;
   return w;
@@ -1866,7 +1897,16 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
     RNNT_CHECK_LAUNCH();
   }
   // 2. hoisted input projection for all timesteps: gates[(t,b)][d*4H + 4j+g] = x(t,b,:) . W_ih'[.] + bias'
-  {
+  const bool x_plain = d->x_sb == I && d->x_st == (int64_t)d->B * I;
+  if (w.hp && x_plain && I >= 32) {  // f16 matrix cores on half-pair operands (gemm_hp.hip)
+    const int64_t M = (int64_t)d->T * d->B, N4 = (int64_t)D * 4 * H;
+    uint32_t* ax = w.hp_amax, *aw = w.hp_amax + 1;
+    if (int rc = hp_amax(d->x, M, I, I, ax, s)) return rc;
+    if (int rc = hp_split(d->x, M, I, I, ax, w.hp_x, s)) return rc;
+    if (int rc = hp_amax(w.wp, N4, I, I, aw, s)) return rc;
+    if (int rc = hp_split(w.wp, N4, I, I, aw, w.hp_w, s)) return rc;
+    if (int rc = hp_gemm(w.hp_x, ax, w.hp_w, aw, M, N4, I, d->gates, 1, N4, 0, w.bp, 0, nullptr, 0, s)) return rc;
+  } else {
     rnnt_gemm_desc g = {};
     g.M = (int64_t)d->T * d->B; g.N = (int64_t)D * 4 * H; g.K = I;
     g.A = d->x; g.a_div = d->B; g.a_so = d->x_st; g.a_si = d->x_sb; g.a_sk = 1; g.a_mc = 0;
@@ -2043,34 +2083,72 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   if (rc) return rc;
 
   const int64_t M = (int64_t)T * B, N4 = (int64_t)D * 4 * H;
+  const bool hp_in = w.hp && I >= 128;   // products with I as an output / contraction width on the f16 matrix cores
+  uint32_t* a_dg = w.hp ? w.hp_amax + 2 : nullptr;
+  if (w.hp) {  // half-pair planes of dG in both orientations (gemm_hp.hip is NT-only: transposed operands are materialised)
+    if ((rc = hp_amax(d->gates, M, N4, N4, a_dg, s))) return rc;
+    if (hp_in && bd->dx)
+      if ((rc = hp_split(d->gates, M, N4, N4, a_dg, w.hp_dg, s))) return rc;
+    if ((rc = hp_split_t(d->gates, N4, M, N4, M, 0, a_dg, w.hp_dgt, s))) return rc;
+  }
   // 2. dX = dG . W_ih'   (needs the permuted weights: rebuild them, the forward copy may have been overwritten)
   if (bd->dx) {
     const long per = (long)4 * H * I;
     hipLaunchKernelGGL(permute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, d->w_ih[0],
                        D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, ngate, w.wp);
     RNNT_CHECK_LAUNCH();
-    rnnt_gemm_desc g = {};
-    g.M = M; g.N = I; g.K = N4;
-    g.A = d->gates; g.a_div = 1; g.a_so = N4; g.a_si = 0; g.a_sk = 1; g.a_mc = 0;
-    g.B = w.wp; g.b_sn = 1; g.b_sk = I;
-    g.C = bd->dx; g.c_div = 1; g.c_so = I; g.c_si = 0;
-    if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
+    if (hp_in) {
+      uint32_t* a_w = w.hp_amax + 3;
+      if ((rc = hp_amax(w.wp, N4, I, I, a_w, s))) return rc;
+      if ((rc = hp_split_t(w.wp, I, N4, I, N4, 0, a_w, w.hp_w, s))) return rc;   // W_ih'^T: (I, contraction N4)
+      if ((rc = hp_gemm(w.hp_dg, a_dg, w.hp_w, a_w, M, I, N4, bd->dx, 1, I, 0, nullptr, 0, nullptr, 0, s))) return rc;
+    } else {
+      rnnt_gemm_desc g = {};
+      g.M = M; g.N = I; g.K = N4;
+      g.A = d->gates; g.a_div = 1; g.a_so = N4; g.a_si = 0; g.a_sk = 1; g.a_mc = 0;
+      g.B = w.wp; g.b_sn = 1; g.b_sk = I;
+      g.C = bd->dx; g.c_div = 1; g.c_so = I; g.c_si = 0;
+      if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
+    }
   }
   // 3. dW_ih' = dG^T . X  (both directions at once), un-permute rows into torch layout
   {
-    rnnt_gemm_desc g = {};
-    g.M = N4; g.N = I; g.K = M;
-    g.A = d->gates; g.a_mc = 1; g.a_sk = N4; g.a_div = 1;
-    g.B = d->x; g.b_sn = 1; g.b_sk = I;
-    g.C = w.wp; g.c_div = 1; g.c_so = I; g.c_si = 0;
-    g.workspace = w.scratch; g.workspace_bytes = w.scratch_bytes;
-    if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
+    if (hp_in) {
+      uint32_t* a_x = w.hp_amax + 4;
+      if ((rc = hp_amax(d->x, M, I, I, a_x, s))) return rc;
+      if ((rc = hp_split_t(d->x, I, M, I, M, 0, a_x, w.hp_x, s))) return rc;     // X^T: (I, contraction T*B)
+      if ((rc = hp_gemm(w.hp_dgt, a_dg, w.hp_x, a_x, N4, I, M, w.wp, 1, I, 0, nullptr, 0, w.scratch, w.scratch_bytes, s))) return rc;
+    } else {
+      rnnt_gemm_desc g = {};
+      g.M = N4; g.N = I; g.K = M;
+      g.A = d->gates; g.a_mc = 1; g.a_sk = N4; g.a_div = 1;
+      g.B = d->x; g.b_sn = 1; g.b_sk = I;
+      g.C = w.wp; g.c_div = 1; g.c_so = I; g.c_si = 0;
+      g.workspace = w.scratch; g.workspace_bytes = w.scratch_bytes;
+      if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
+    }
     const long per = (long)4 * H * I;
     hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per, ngate,
                        bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0], acc);
     RNNT_CHECK_LAUNCH();
   }
   // 4. dW_hh'[d] = sum_t dG[t]^T . h_prev(t): time-shifted views of dG and y (padded frames are zero in both)
+  if (w.hp && T > 1) {
+    uint32_t* a_y = w.hp_amax + 5;
+    if ((rc = hp_amax(d->y, M, (int64_t)D * H, (int64_t)D * H, a_y, s))) return rc;
+    if (gru) {  // hidden-side gate gradients differ from the input-side ones in the n gate: their own transposed planes
+      if ((rc = hp_amax(ghid, M, N4, N4, a_dg, s))) return rc;
+      if ((rc = hp_split_t(ghid, N4, M, N4, M, 0, a_dg, w.hp_dgt, s))) return rc;
+    }
+    for (int dir = 0; dir < D; ++dir) {
+      // h_prev of frame t is y[t-1] (forward direction) / y[t+1] (reverse): plane row j, index k = y[k -/+ B][dir*H + j], zero outside
+      char* yt = w.hp_yt + (size_t)dir * hp_plane_bytes(H, M);
+      if ((rc = hp_split_t(d->y + (int64_t)dir * H, H, M, (int64_t)D * H, M, dir == 0 ? -B : B, a_y, yt, s))) return rc;
+      const char* ag = w.hp_dgt + (size_t)dir * 4 * H * (size_t)ceil_div(M, 32) * 128;
+      if ((rc = hp_gemm(ag, a_dg, yt, a_y, 4 * H, H, M, w.dwhh + (int64_t)dir * 4 * H * H, 1, H, 0, nullptr, 0, w.scratch, w.scratch_bytes, s)))
+        return rc;
+    }
+  } else
   for (int dir = 0; dir < D; ++dir) {
     rnnt_gemm_desc g = {};
     g.M = 4 * H; g.N = H; g.K = (int64_t)(T - 1) * B;

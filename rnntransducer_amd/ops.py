@@ -114,6 +114,59 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, B: torch.Tensor, Cout: torch.T
     check(_lib.lib().rnnt_hip_gemm_f32(C.byref(d), _stream()), "rnnt_hip_gemm_f32")
 
 
+# --------------------------------------------------------------------------------------------------
+# half-pair (hp) operands + the f16-MFMA GEMM on them (include/rnnt_hip.h).  The LSTM entry points use these internally for
+# their big products; exposed here for tests and tools.
+# --------------------------------------------------------------------------------------------------
+class HpTensor:
+    """hp planes of an fp32 matrix (rows x K): device byte buffer + the device amax word the scale derives from."""
+
+    def __init__(self, rows: int, K: int, device):
+        self.rows, self.K = int(rows), int(K)
+        n = _lib.lib().rnnt_hip_hp_bytes(self.rows, self.K)
+        self.planes = torch.empty(max(n, 128), device=device, dtype=torch.uint8)
+        self.amax = torch.zeros(1, device=device, dtype=torch.int32)
+
+
+def hp_split(x: torch.Tensor, transpose: bool = False, shift: int = 0, K: Optional[int] = None) -> HpTensor:
+    """x (rows, K) fp32 -> HpTensor(rows, K).  transpose=True: x is (src_rows, rows); plane row r, index k = x[k + shift, r]
+    (zero outside the source), contraction length K (default src_rows)."""
+    _need_gpu(x)
+    x = _f32c(x, "x")
+    if x.dim() != 2:
+        raise ValueError("hp_split takes a 2-D tensor")
+    if not transpose:
+        rows, kk = x.shape
+        t = HpTensor(rows, kk, x.device)
+        check(_lib.lib().rnnt_hip_hp_split(_addr(x), rows, kk, kk, 0, 0, 0, _addr(t.planes), _addr(t.amax), 0, _stream()), "hp_split")
+        return t
+    src_rows, rows = x.shape
+    kk = src_rows if K is None else int(K)
+    t = HpTensor(rows, kk, x.device)
+    check(_lib.lib().rnnt_hip_hp_split(_addr(x), rows, kk, rows, 1, src_rows, int(shift), _addr(t.planes), _addr(t.amax), 0, _stream()),
+          "hp_split")
+    return t
+
+
+def gemm_hp(a: HpTensor, b: HpTensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+            accumulate: bool = False, split_k: bool = True) -> torch.Tensor:
+    """C (M, N) [+]= A (M, K) . B (N, K)^T + bias on hp operands."""
+    if a.K != b.K:
+        raise ValueError(f"contraction lengths differ: {a.K} vs {b.K}")
+    M, N, K = a.rows, b.rows, a.K
+    if out is None:
+        out = torch.empty(M, N, device=a.planes.device, dtype=torch.float32)
+    if tuple(out.shape) != (M, N) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError(f"out must be a contiguous float32 ({M}, {N}) tensor")
+    if bias is not None and tuple(bias.shape) != (N,):
+        raise ValueError(f"bias must be ({N},)")
+    nws = _lib.lib().rnnt_hip_gemm_hp_workspace_bytes(M, N, K) if split_k else 0
+    ws = torch.empty(nws, device=out.device, dtype=torch.uint8) if nws else None
+    check(_lib.lib().rnnt_hip_gemm_hp(_addr(a.planes), _addr(a.amax), _addr(b.planes), _addr(b.amax), M, N, K, _addr(out), N, _addr(bias),
+                                      GEMM_ACCUM if accumulate else 0, _addr(ws), nws, _stream()), "rnnt_hip_gemm_hp")
+    return out
+
+
 def colsum(X: torch.Tensor, M: int, N: int, ld: Optional[int] = None, into: Optional[torch.Tensor] = None):
     """Column sums of X (M,N).  `into`: add them to this (N,) tensor (a flat-gradient view) and return None."""
     out = torch.empty(N, device=X.device, dtype=torch.float32) if into is None else into

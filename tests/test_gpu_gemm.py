@@ -185,3 +185,72 @@ def test_gemm_split_pieces_are_exact_on_hard_values(gemm_mode_env):
     out = torch.empty(M, N, device="cuda")
     gemm(M, N, 16, A.cuda(), W.cuda(), out)
     assert torch.equal(out.cpu(), A[:, 3:4] * W[:, 3:4].T)  # power-of-two multipliers: exact in fp32
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# half-pair (hp) operands + the f16-MFMA GEMM (csrc/gemm_hp.hip)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (300, 257, 45), (1000, 520, 1024), (512, 256, 4096), (33, 700, 96), (1, 1, 1)])
+def test_gemm_hp_matches_fp64(M, N, K):
+    """C = A . B^T on hp operands against an fp64 product of the same fp32 inputs, wide dynamic range (rows of A over six
+    decades): error relative to sum |a||b| no worse than the exact fp32 fma chain's bound; ragged edges in M, N and K."""
+    from rnntransducer_amd.ops import gemm_hp, hp_split
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.empty(M, 1).uniform_(-14, 3, generator=g))
+    W = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T
+    scale = A.abs().double() @ W.abs().double().T + 1e-30
+    out = gemm_hp(hp_split(A.cuda()), hp_split(W.cuda()))
+    err = ((out.double().cpu() - ref).abs() / scale).max().item()
+    assert err < 2e-6, err
+    # bias + accumulate epilogues
+    base = torch.randn(M, N, generator=g)
+    out2 = base.clone().cuda()
+    gemm_hp(hp_split(A.cuda()), hp_split(W.cuda()), out=out2, bias=bias.cuda(), accumulate=True)
+    ref2 = ref + bias.double() + base.double()
+    assert ((out2.double().cpu() - ref2).abs() / (scale + ref2.abs())).max().item() < 2e-6
+
+
+def test_gemm_hp_transposed_and_shifted_operands_split_k():
+    """The weight-gradient form: dW = dG^T . X with both operands given row-major over the contraction index (transposed split),
+    deep K (deterministic split-K slabs), and the time-shifted operand of dW_hh (zero fill outside the source)."""
+    from rnntransducer_amd.ops import gemm_hp, hp_split
+    g = torch.Generator().manual_seed(9)
+    Kc, M, N, shift = 5000, 512, 260, 17
+    dG = torch.randn(Kc, M, generator=g) * torch.exp(torch.empty(Kc, 1).uniform_(-10, 0, generator=g))
+    X = torch.randn(Kc, N, generator=g)
+    a, b = hp_split(dG.cuda(), transpose=True), hp_split(X.cuda(), transpose=True)
+    out = gemm_hp(a, b)
+    ref = dG.double().T @ X.double()
+    scale = dG.abs().double().T @ X.abs().double()
+    assert ((out.double().cpu() - ref).abs() / scale).max().item() < 2e-6
+    assert torch.equal(out, gemm_hp(a, b))                       # split-K slabs are summed in a fixed order
+    for sh in (shift, -shift):
+        bs = hp_split(X.cuda(), transpose=True, shift=sh)
+        Xs = torch.zeros_like(X)
+        if sh > 0:
+            Xs[:Kc - sh] = X[sh:]
+        else:
+            Xs[-sh:] = X[:Kc + sh]
+        refs = dG.double().T @ Xs.double()
+        assert ((gemm_hp(a, bs).double().cpu() - refs).abs() / scale).max().item() < 2e-6
+
+
+def test_hp_split_represents_fp32_to_two_ulp_and_handles_extremes():
+    """hi + lo reproduces x * scale to 2^-23 relative (|x| within 2^17 of amax) and to 2^-40 amax below; zeros, a zero tensor
+    and values near the fp32 extremes survive (one-term products against 1.0)."""
+    from rnntransducer_amd.ops import gemm_hp, hp_split
+    vals = torch.tensor([1.0, -1.0, 1.0 + 2 ** -11, 1.0 + 2 ** -12, 1.0 + 2 ** -23, 2.0 - 2 ** -23, 0.3333333, -0.1, 3.0e-5, 7.1e-6, 0.0,
+                         1.5e-7, 65504.0 / 65536, 2 ** -20, -(2 ** -24) * 1.7])
+    for mag in (1.0, 1e-30, 1e30):
+        A = torch.zeros(len(vals), 32)
+        A[:, 0] = vals * mag
+        one = torch.zeros(1, 32)
+        one[0, 0] = 1.0
+        out = gemm_hp(hp_split(A.cuda()), hp_split(one.cuda())).cpu().flatten()
+        amax = (vals * mag).abs().max().item()
+        tol = (vals * mag).abs() * 2.0 ** -22 + amax * 2.0 ** -39
+        assert torch.all((out.double() - (vals * mag).double()).abs() <= tol.double()), (mag, out, vals * mag)
+    z = gemm_hp(hp_split(torch.zeros(4, 40).cuda()), hp_split(torch.ones(3, 40).cuda()))
+    assert torch.all(z == 0)

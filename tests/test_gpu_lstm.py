@@ -157,6 +157,18 @@ def test_lstm_v2_lds_resident_kernels_still_match(monkeypatch, B, T, I, H, L, bi
     test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
 
 
+@pytest.mark.parametrize("B,T,I,H,L,bi", [(32, 40, 144, 128, 2, True), (32, 33, 80, 256, 2, False), (64, 17, 128, 512, 1, True)])
+def test_lstm_big_products_on_half_pair_operands(monkeypatch, B, T, I, H, L, bi):
+    """The hp path (gemm_hp.hip: input projection, dX, dW_ih, dW_hh on the f16 matrix cores) forced on at sizes the oracle
+    finishes quickly — ragged T*B (not a multiple of 256), I not a multiple of 32, one and two directions; and the same
+    shapes with it disabled (RNNT_GEMM_NO_HP)."""
+    monkeypatch.setenv("RNNT_GEMM_FORCE_HP", "1")
+    test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
+    monkeypatch.delenv("RNNT_GEMM_FORCE_HP")
+    monkeypatch.setenv("RNNT_GEMM_NO_HP", "1")
+    test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
+
+
 def test_xcd_local_exchange_is_bitwise_identical_to_write_through(monkeypatch):
     """B=32, H=512, bidirectional -> 8 sync groups x 32 workgroups = the BASELINE config-2 decomposition.  When a group
     is verified to sit on one XCD it exchanges through that XCD's L2 (plain stores); otherwise / when disabled it uses
@@ -232,6 +244,13 @@ def test_gru_and_elman_cells_fwd_bwd(cell, B, T, I, H, L, bi):
     close("dx", x_tm.grad.transpose(0, 1), ref_dx)
     for name, p in ref.named_parameters():
         close(name, getattr(hip, name).grad, p.grad)
+
+
+@pytest.mark.parametrize("cell", ["gru", "rnn_tanh"])
+def test_gru_and_elman_cells_on_half_pair_operands(monkeypatch, cell):
+    """GRU's hidden-side gate gradients take their own transposed planes for dW_hh; Elman cells use one of four gate slots."""
+    monkeypatch.setenv("RNNT_GEMM_FORCE_HP", "1")
+    test_gru_and_elman_cells_fwd_bwd(cell, 32, 35, 136, 128, 2, True)
 
 
 def test_batches_beyond_one_launch_are_split_along_b():
