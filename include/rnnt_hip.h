@@ -108,12 +108,14 @@ int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream);
  * inside rnnt_hip_lstm_fwd / _bwd (hoisted input projection of nn.LSTM, networks/encoder.py:67-75,99, and its backward
  * products dX, dW_ih, dW_hh): 3 instead of 6 MFMA products per fp32 product, operands streamed to LDS by LDS-DMA.
  *
- * hp planes of an fp32 tensor x (rows x K): amax = max|x| (a device word the split writes, or the caller supplies),
- *   v = x * 2^(14 - floor(log2 amax)),  hi = fp16_rn(v),  lo = fp16_rn(v - hi)   (v = hi + lo to 2^-23 |v|, 2^-40 amax floor)
- *   layout: row-major, K padded to 32, one 128-byte line per (row, 32-k block): 32 hi | 32 lo.  rnnt_hip_hp_bytes(rows, K).
- * rnnt_hip_hp_split: transpose == 0: x is (rows x K), row stride ld.  transpose == 1: x is (src_rows x >= rows), row stride
- *   ld; plane row r, index k holds x[k + shift][r] (0 outside [0, src_rows)) — the transposed operands of the weight-gradient
- *   products, time-shifted for dW_hh.  amax_given == 0: the split first computes amax over the source view.
+ * hp planes of an fp32 matrix x (rows x K), scaled per row: amax[r] = max_k |x[r][k]| (fp32 bit patterns, `rows` device words
+ *   next to the planes), v = x * 2^(14 - floor(log2 amax[r])), hi = fp16_rn(v), lo = fp16_rn(v - hi)
+ *   (v = hi + lo to 2^-23 |v|, with a floor of 2^-40 amax[r]); layout: row-major, K padded to 32, one 128-byte line per
+ *   (row, 32-k block): 32 hi | 32 lo.  rnnt_hip_hp_bytes(rows, K).
+ * rnnt_hip_hp_split: transpose == 0: x is (rows x K), row stride ld; amax[rows] is written (amax_given must be 0).
+ *   transpose == 1: x is (src_rows x >= rows), row stride ld; plane row r, index k holds x[k + shift][r] (0 outside
+ *   [0, src_rows)) — the transposed operands of the weight-gradient products, time-shifted for dW_hh; amax[r] = maximum of source
+ *   column r, computed here unless amax_given.
  * rnnt_hip_gemm_hp: C (M x N, row stride ldc) [+]= A (M x K) . B (N x K)^T + bias, both operands hp planes (NT form), fp32 out.
  *   flags: RNNT_GEMM_ACCUM.  workspace (optional, rnnt_hip_gemm_hp_workspace_bytes): deterministic split-K slabs.
  * ---------------------------------------------------------------------------------------------- */

@@ -45,8 +45,8 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // half-pair (hp) operands and the f16-MFMA GEMM on them (gemm_hp.hip); used by lstm.hip for its big products
 size_t hp_plane_bytes(int64_t rows, int64_t K);
-int hp_amax(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, hipStream_t s);
-int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, const uint32_t* amax, void* planes, hipStream_t s);
+int hp_colmax(const float* x, int64_t rows, int64_t C, int64_t ld, uint32_t* amax, hipStream_t s);   // amax[C] of the columns
+int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, void* planes, hipStream_t s);  // writes amax[rows]
 int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, int64_t shift, const uint32_t* amax, void* planes,
                hipStream_t s);
 size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);

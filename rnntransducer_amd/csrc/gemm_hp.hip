@@ -6,11 +6,12 @@
 // (autograd of the same lines) — 95 % of the step's GEMM FLOPs at BASELINE configs[1].  Small / oddly shaped products
 // (out_proj, joint pre-GEMMs, K < 256) stay on gemm.hip.
 //
-// hp format of an fp32 tensor x (rows x K) with amax = max|x|:  s = 2^(14 - floor(log2 amax)), v = x * s  (|v| < 2^15),
-//   hi = fp16_rn(v),  lo = fp16_rn(v - hi)   =>   v = hi + lo + e,  |e| <= 2^-23 |v|   (11 + 1 + 11 significant bits)
-//   stored row-major, K padded to 32, per (row, 32-k block) ONE 128-byte line: 32 x hi | 32 x lo.
-// Values more than 2^17 below amax lose relative (not absolute) precision: |e| <= 2^-40 amax — below the fp32 rounding of
-// any sum the large elements take part in.  a.b ~= s_a^-1 s_b^-1 (a_lo b_hi + a_hi b_lo + a_hi b_hi): the dropped a_lo b_lo is
+// hp format of an fp32 matrix x (rows x K), scaled PER ROW: amax_r = max_k |x[r][k]|, s_r = 2^(14 - floor(log2 amax_r)),
+//   v = x * s_r (|v| < 2^15),  hi = fp16_rn(v),  lo = fp16_rn(v - hi)  =>  v = hi + lo + e,  |e| <= 2^-23 |v|  (11 + 1 + 11 bits)
+//   stored row-major, K padded to 32, per (row, 32-k block) ONE 128-byte line: 32 x hi | 32 x lo; amax_r (fp32 bits) in a
+//   side array.  Row scales factor out of a dot product (C[m][n] = s_m^-1 s_n^-1 sum_k a'b'), so every row keeps full relative
+//   precision whatever the other rows hold; inside a row, values more than 2^17 below the row's amax lose relative (not absolute)
+//   precision: |e| <= 2^-40 amax_r — below the fp32 rounding of any sum the row's large elements take part in.  a.b ~= s_a^-1 s_b^-1 (a_lo b_hi + a_hi b_lo + a_hi b_hi): the dropped a_lo b_lo is
 // <= 2^-22 |a b|, typically 2^-25; products and sums are exact / fp32-accumulated in the MFMA.  Measured against fp64:
 // tests/test_gpu_gemm.py::test_gemm_hp_*.
 //
@@ -49,25 +50,18 @@ __device__ __forceinline__ float hp_inv_scale_from_amax(unsigned amax_bits) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// amax: max |x| over a (rows x K) view with row stride ld, as the bit pattern of the non-negative float (atomicMax on
-// unsigned orders them like the floats)
+// column maxima of |x| over a (rows x C) view with row stride ld, as bit patterns of non-negative floats (atomicMax on unsigned
+// orders them like the floats; max is order-independent, so the result is deterministic).  out must be zeroed.
+// grid (ceil(C/256), row chunks)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) hp_amax_kernel(const float* __restrict__ x, long rows, int K, long ld, unsigned* __restrict__ out) {
+__global__ void __launch_bounds__(256) hp_colmax_kernel(const float* __restrict__ x, long rows, int C, long ld, long rows_per_chunk,
+                                                        unsigned* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   unsigned m = 0;
-  const long total = rows * (long)K;
-  if (ld == K && (K & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    const long n4 = total >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-      const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
-      m = max(max(m, v[0] & 0x7fffffffu), max(max(v[1] & 0x7fffffffu, v[2] & 0x7fffffffu), v[3] & 0x7fffffffu));
-    }
-  } else {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
-      m = max(m, __float_as_uint(x[(i / K) * ld + (i % K)]) & 0x7fffffffu);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(out, m);
+  for (long r = r0; r < r1; ++r) m = max(m, __float_as_uint(x[r * ld + c]) & 0x7fffffffu);
+  if (m != 0) atomicMax(out + c, m);
 }
 
 __device__ __forceinline__ void hp_split8(const float (&x)[8], float scale, u32x4& hi, u32x4& lo) {
@@ -83,41 +77,59 @@ __device__ __forceinline__ void hp_split8(const float (&x)[8], float scale, u32x
   lo = __builtin_bit_cast(u32x4, l);
 }
 
-// x (rows x K, row stride ld) -> planes[rows][Kp/32][hi 32 | lo 32]; one thread per (row, 8-k chunk)
-__global__ void __launch_bounds__(256) hp_split_kernel(const float* __restrict__ x, long rows, int K, long ld, const unsigned* __restrict__ amax,
+// x (rows x K, row stride ld) -> planes[rows][Kp/32][hi 32 | lo 32] + amax[rows]; ONE WAVE per row: pass 1 row maximum
+// (wave reduce), pass 2 scale + split (the row is re-read from L1/L2)
+__global__ void __launch_bounds__(256) hp_split_kernel(const float* __restrict__ x, long rows, int K, long ld, unsigned* __restrict__ amax,
                                                        char* __restrict__ out) {
   const int Kp = (K + 31) & ~31, cpr = Kp >> 3;
-  const long total = rows * cpr;
-  const float scale = hp_scale_from_amax(*amax);
+  const int lane = threadIdx.x & 63;
   const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long r = i / cpr;
-    const int c = (int)(i % cpr), k = 8 * c;
-    const float* src = x + r * ld + k;
-    float v[8];
-    if (vec && k + 7 < K) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    } else {
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    const float* row = x + r * ld;
+    unsigned m = 0;
+    for (int c = lane; c < cpr; c += 64) {
+      const int k = 8 * c;
+      if (vec && k + 7 < K) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(row + k), b = *reinterpret_cast<const u32x4*>(row + k + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? src[e] : 0.f;
+        for (int e = 0; e < 4; ++e) m = max(m, max(a[e] & 0x7fffffffu, b[e] & 0x7fffffffu));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k + e < K) m = max(m, __float_as_uint(row[k + e]) & 0x7fffffffu);
+      }
     }
-    u32x4 hi, lo;
-    hp_split8(v, scale, hi, lo);
-    char* dst = out + (r * (Kp >> 5) + (c >> 2)) * 128 + 16 * (c & 3);
-    *reinterpret_cast<u32x4*>(dst) = hi;
-    *reinterpret_cast<u32x4*>(dst + 64) = lo;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0) amax[r] = m;
+    const float scale = hp_scale_from_amax(m);
+    for (int c = lane; c < cpr; c += 64) {
+      const int k = 8 * c;
+      float v[8];
+      if (vec && k + 7 < K) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row + k), b = *reinterpret_cast<const f32x4*>(row + k + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (k + e < K) ? row[k + e] : 0.f;
+      }
+      u32x4 hi, lo;
+      hp_split8(v, scale, hi, lo);
+      char* dst = out + (r * (Kp >> 5) + (c >> 2)) * 128 + 16 * (c & 3);
+      *reinterpret_cast<u32x4*>(dst) = hi;
+      *reinterpret_cast<u32x4*>(dst + 64) = lo;
+    }
   }
 }
 
 // transposed: x is (Ksrc rows x >= R cols, row stride ld); planes row r (= source column c0 + r), contraction index k in [0, K):
-// value x[k + shift][c0 + r] (0 when k + shift is outside [0, Ksrc)).  Workgroup = 32 k x 256 source columns through LDS.
+// value x[k + shift][c0 + r] (0 when k + shift is outside [0, Ksrc)), scaled by amax[r] (the source column's maximum: hp_colmax).
+// Workgroup = 32 k x 256 source columns through LDS.
 __global__ void __launch_bounds__(256) hp_split_t_kernel(const float* __restrict__ x, int R, int K, long ld, int Ksrc, int shift,
                                                          const unsigned* __restrict__ amax, char* __restrict__ out) {
   __shared__ float tile[32][257];
   const int kb = blockIdx.x, r0 = blockIdx.y * 256;
   const int tid = threadIdx.x;
-  const float scale = hp_scale_from_amax(*amax);
   // load: pass q covers source rows 4q..4q+3, each row 64 threads x 4 columns
   const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 #pragma unroll
@@ -150,7 +162,7 @@ __global__ void __launch_bounds__(256) hp_split_t_kernel(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tile[8 * ch + e][rl];
       u32x4 hi, lo;
-      hp_split8(v, scale, hi, lo);
+      hp_split8(v, hp_scale_from_amax(amax[r0 + rl]), hi, lo);   // per output row (= source column) scale
       char* dst = out + ((long)(r0 + rl) * Kp32 + kb) * 128 + 16 * ch;
       *reinterpret_cast<u32x4*>(dst) = hi;
       *reinterpret_cast<u32x4*>(dst + 64) = lo;
@@ -270,14 +282,14 @@ __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
   }
 
   // epilogue: D block (i, j): lane -> rows 4*(lane>>4) + reg, column lane&15
-  const float scale = hp_inv_scale_from_amax(*p.a_amax) * hp_inv_scale_from_amax(*p.b_amax);
   const int mode = p.splits > 1 ? 0 : ((p.flags & RNNT_GEMM_ACCUM) ? 2 : 1);  // uniform: slab | store | accumulate
   float* slab = p.splits > 1 ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
-  float bias_v[4];
+  float bias_v[4], sb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wc * 64 + j * 16 + (lane & 15);
     bias_v[j] = (mode != 0 && p.bias && n < p.N) ? p.bias[n] : 0.f;
+    sb[j] = hp_inv_scale_from_amax(p.b_amax[min(n, p.N - 1)]);
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -286,6 +298,7 @@ __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
       const int m = m0 + wr * 128 + i * 16 + 4 * (lane >> 4) + reg;
       const bool mok = m < p.M;
       const int mc = mok ? m : 0;
+      const float sa = hp_inv_scale_from_amax(p.a_amax[mc]);
       float* crow = mode == 0 ? slab + (long)mc * p.N : p.C + (long)(mc / p.c_div) * p.c_so + (long)(mc % p.c_div) * p.c_si;
       float old[4] = {0.f, 0.f, 0.f, 0.f};
       if (mode == 2) {
@@ -298,7 +311,7 @@ __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + wc * 64 + j * 16 + (lane & 15);
-        if (mok && n < p.N) crow[n] = acc[i][j][reg] * scale + bias_v[j] + old[j];
+        if (mok && n < p.N) crow[n] = acc[i][j][reg] * sa * sb[j] + bias_v[j] + old[j];
       }
     }
   }
@@ -322,23 +335,25 @@ __global__ void __launch_bounds__(256) hp_splitk_reduce_kernel(const HpGemmK p) 
 // internal entry points shared with lstm.hip -------------------------------------------------------------------------
 size_t hp_plane_bytes(int64_t rows, int64_t K) { return (size_t)rows * (size_t)ceil_div(K, 32) * 128; }
 
-int hp_amax(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, hipStream_t s) {
-  RNNT_CHECK_HIP(hipMemsetAsync(amax, 0, 4, s));
-  const long total = rows * K;
-  if (total == 0) return RNNT_OK;
-  const long blocks = ceil_div(ceil_div(total, 4), 256);
-  ProfScope prof(RNNT_K_MISC, 4.0 * (double)total, s);
-  hipLaunchKernelGGL(hp_amax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, x, (long)rows, (int)K, (long)ld, amax);
+int hp_colmax(const float* x, int64_t rows, int64_t C, int64_t ld, uint32_t* amax, hipStream_t s) {
+  RNNT_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)C * 4, s));
+  if (rows == 0 || C == 0) return RNNT_OK;
+  long chunks = ceil_div(2048, ceil_div(C, 256));
+  if (chunks > ceil_div(rows, 64)) chunks = ceil_div(rows, 64);
+  if (chunks < 1) chunks = 1;
+  const long rpc = ceil_div(rows, chunks);
+  ProfScope prof(RNNT_K_MISC, 4.0 * (double)rows * (double)C, s);
+  hipLaunchKernelGGL(hp_colmax_kernel, dim3((unsigned)ceil_div(C, 256), (unsigned)ceil_div(rows, rpc)), dim3(256), 0, s, x, (long)rows, (int)C,
+                     (long)ld, rpc, amax);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }
 
-int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, const uint32_t* amax, void* planes, hipStream_t s) {
+int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, void* planes, hipStream_t s) {
   if (rows == 0) return RNNT_OK;
-  const long total = rows * ceil_div(K, 32) * 4;
-  const long blocks = ceil_div(total, 256);
+  const long blocks = ceil_div(rows, 4);
   ProfScope prof(RNNT_K_MISC, 8.0 * (double)rows * (double)K, s);
-  hipLaunchKernelGGL(hp_split_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, x, (long)rows, (int)K, (long)ld, amax,
+  hipLaunchKernelGGL(hp_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, x, (long)rows, (int)K, (long)ld, amax,
                      (char*)planes);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
@@ -425,13 +440,12 @@ extern "C" int rnnt_hip_hp_split(const float* x, int64_t rows, int64_t K, int64_
   hipStream_t s = (hipStream_t)stream;
   if (!transpose) {
     RNNT_CHECK_ARG(ld >= K, "hp_split: ld < K");
-    if (!amax_given)
-      if (int rc = hp_amax(x, rows, K, ld, amax, s)) return rc;
+    RNNT_CHECK_ARG(!amax_given, "hp_split: the row-major split computes its row maxima itself");
     return hp_split(x, rows, K, ld, amax, planes, s);
   }
   RNNT_CHECK_ARG(ld >= rows && src_rows >= 1, "hp_split: transposed source is (src_rows x >= rows), ld >= rows");
   if (!amax_given)
-    if (int rc = hp_amax(x, src_rows, rows, ld, amax, s)) return rc;
+    if (int rc = hp_colmax(x, src_rows, rows, ld, amax, s)) return rc;
   return hp_split_t(x, rows, K, ld, src_rows, shift, amax, planes, s);
 }
 

@@ -1532,7 +1532,7 @@ struct LstmWs {
   char* hp_dg;   // bwd: dG (T*B, D*4H)
   char* hp_dgt;  // bwd: dG^T (D*4H, T*B)
   char* hp_yt;   // bwd: time-shifted h^T per direction (D, H, T*B)
-  uint32_t* hp_amax;  // 8 device words
+  uint32_t* hp_amax;  // per-row maxima of the operands: [M | N4 | M | N4 | I | I | D*H] words (carve_lstm)
   size_t total;
 };
 
@@ -1697,7 +1697,7 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
     w.hp_x = w.hp_w = w.hp_dg = w.hp_dgt = w.hp_yt = nullptr;
     w.hp_amax = nullptr;
     if (w.hp) {
-      w.hp_amax = reinterpret_cast<uint32_t*>(take(256));
+      w.hp_amax = reinterpret_cast<uint32_t*>(take((size_t)(2 * M + 2 * N4 + 2 * I + (int64_t)D * H) * 4));
       w.hp_x = take(hp_plane_bytes(M, I) > hp_plane_bytes(I, M) ? hp_plane_bytes(M, I) : hp_plane_bytes(I, M));
       w.hp_w = take(hp_plane_bytes(N4, I) > hp_plane_bytes(I, N4) ? hp_plane_bytes(N4, I) : hp_plane_bytes(I, N4));
       w.hp_dg = take(hp_plane_bytes(M, N4));
@@ -1900,10 +1900,8 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   const bool x_plain = d->x_sb == I && d->x_st == (int64_t)d->B * I;
   if (w.hp && x_plain && I >= 32) {  // f16 matrix cores on half-pair operands (gemm_hp.hip)
     const int64_t M = (int64_t)d->T * d->B, N4 = (int64_t)D * 4 * H;
-    uint32_t* ax = w.hp_amax, *aw = w.hp_amax + 1;
-    if (int rc = hp_amax(d->x, M, I, I, ax, s)) return rc;
+    uint32_t* ax = w.hp_amax, *aw = w.hp_amax + M;
     if (int rc = hp_split(d->x, M, I, I, ax, w.hp_x, s)) return rc;
-    if (int rc = hp_amax(w.wp, N4, I, I, aw, s)) return rc;
     if (int rc = hp_split(w.wp, N4, I, I, aw, w.hp_w, s)) return rc;
     if (int rc = hp_gemm(w.hp_x, ax, w.hp_w, aw, M, N4, I, d->gates, 1, N4, 0, w.bp, 0, nullptr, 0, s)) return rc;
   } else {
@@ -2084,12 +2082,17 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
 
   const int64_t M = (int64_t)T * B, N4 = (int64_t)D * 4 * H;
   const bool hp_in = w.hp && I >= 128;   // products with I as an output / contraction width on the f16 matrix cores
-  uint32_t* a_dg = w.hp ? w.hp_amax + 2 : nullptr;
+  // per-row maxima: dG rows | dG columns | W_ih'^T rows | X^T rows | h^T rows
+  uint32_t* a_dgr = w.hp ? w.hp_amax + M + N4 : nullptr;
+  uint32_t* a_dgc = w.hp ? a_dgr + M : nullptr;
+  uint32_t* a_w = w.hp ? a_dgc + N4 : nullptr;
+  uint32_t* a_x = w.hp ? a_w + I : nullptr;
+  uint32_t* a_y = w.hp ? a_x + I : nullptr;
   if (w.hp) {  // half-pair planes of dG in both orientations (gemm_hp.hip is NT-only: transposed operands are materialised)
-    if ((rc = hp_amax(d->gates, M, N4, N4, a_dg, s))) return rc;
     if (hp_in && bd->dx)
-      if ((rc = hp_split(d->gates, M, N4, N4, a_dg, w.hp_dg, s))) return rc;
-    if ((rc = hp_split_t(d->gates, N4, M, N4, M, 0, a_dg, w.hp_dgt, s))) return rc;
+      if ((rc = hp_split(d->gates, M, N4, N4, a_dgr, w.hp_dg, s))) return rc;
+    if ((rc = hp_colmax(d->gates, M, N4, N4, a_dgc, s))) return rc;
+    if ((rc = hp_split_t(d->gates, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
   }
   // 2. dX = dG . W_ih'   (needs the permuted weights: rebuild them, the forward copy may have been overwritten)
   if (bd->dx) {
@@ -2098,10 +2101,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
                        D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, ngate, w.wp);
     RNNT_CHECK_LAUNCH();
     if (hp_in) {
-      uint32_t* a_w = w.hp_amax + 3;
-      if ((rc = hp_amax(w.wp, N4, I, I, a_w, s))) return rc;
+      if ((rc = hp_colmax(w.wp, N4, I, I, a_w, s))) return rc;
       if ((rc = hp_split_t(w.wp, I, N4, I, N4, 0, a_w, w.hp_w, s))) return rc;   // W_ih'^T: (I, contraction N4)
-      if ((rc = hp_gemm(w.hp_dg, a_dg, w.hp_w, a_w, M, I, N4, bd->dx, 1, I, 0, nullptr, 0, nullptr, 0, s))) return rc;
+      if ((rc = hp_gemm(w.hp_dg, a_dgr, w.hp_w, a_w, M, I, N4, bd->dx, 1, I, 0, nullptr, 0, nullptr, 0, s))) return rc;
     } else {
       rnnt_gemm_desc g = {};
       g.M = M; g.N = I; g.K = N4;
@@ -2114,10 +2116,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   // 3. dW_ih' = dG^T . X  (both directions at once), un-permute rows into torch layout
   {
     if (hp_in) {
-      uint32_t* a_x = w.hp_amax + 4;
-      if ((rc = hp_amax(d->x, M, I, I, a_x, s))) return rc;
+      if ((rc = hp_colmax(d->x, M, I, I, a_x, s))) return rc;
       if ((rc = hp_split_t(d->x, I, M, I, M, 0, a_x, w.hp_x, s))) return rc;     // X^T: (I, contraction T*B)
-      if ((rc = hp_gemm(w.hp_dgt, a_dg, w.hp_x, a_x, N4, I, M, w.wp, 1, I, 0, nullptr, 0, w.scratch, w.scratch_bytes, s))) return rc;
+      if ((rc = hp_gemm(w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, M, w.wp, 1, I, 0, nullptr, 0, w.scratch, w.scratch_bytes, s))) return rc;
     } else {
       rnnt_gemm_desc g = {};
       g.M = N4; g.N = I; g.K = M;
@@ -2134,18 +2135,18 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   }
   // 4. dW_hh'[d] = sum_t dG[t]^T . h_prev(t): time-shifted views of dG and y (padded frames are zero in both)
   if (w.hp && T > 1) {
-    uint32_t* a_y = w.hp_amax + 5;
-    if ((rc = hp_amax(d->y, M, (int64_t)D * H, (int64_t)D * H, a_y, s))) return rc;
+    if ((rc = hp_colmax(d->y, M, (int64_t)D * H, (int64_t)D * H, a_y, s))) return rc;
     if (gru) {  // hidden-side gate gradients differ from the input-side ones in the n gate: their own transposed planes
-      if ((rc = hp_amax(ghid, M, N4, N4, a_dg, s))) return rc;
-      if ((rc = hp_split_t(ghid, N4, M, N4, M, 0, a_dg, w.hp_dgt, s))) return rc;
+      if ((rc = hp_colmax(ghid, M, N4, N4, a_dgc, s))) return rc;
+      if ((rc = hp_split_t(ghid, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
     }
     for (int dir = 0; dir < D; ++dir) {
       // h_prev of frame t is y[t-1] (forward direction) / y[t+1] (reverse): plane row j, index k = y[k -/+ B][dir*H + j], zero outside
       char* yt = w.hp_yt + (size_t)dir * hp_plane_bytes(H, M);
-      if ((rc = hp_split_t(d->y + (int64_t)dir * H, H, M, (int64_t)D * H, M, dir == 0 ? -B : B, a_y, yt, s))) return rc;
+      if ((rc = hp_split_t(d->y + (int64_t)dir * H, H, M, (int64_t)D * H, M, dir == 0 ? -B : B, a_y + (int64_t)dir * H, yt, s))) return rc;
       const char* ag = w.hp_dgt + (size_t)dir * 4 * H * (size_t)ceil_div(M, 32) * 128;
-      if ((rc = hp_gemm(ag, a_dg, yt, a_y, 4 * H, H, M, w.dwhh + (int64_t)dir * 4 * H * H, 1, H, 0, nullptr, 0, w.scratch, w.scratch_bytes, s)))
+      if ((rc = hp_gemm(ag, a_dgc + (int64_t)dir * 4 * H, yt, a_y + (int64_t)dir * H, 4 * H, H, M, w.dwhh + (int64_t)dir * 4 * H * H, 1, H, 0,
+                        nullptr, 0, w.scratch, w.scratch_bytes, s)))
         return rc;
     }
   } else

@@ -119,13 +119,13 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, B: torch.Tensor, Cout: torch.T
 # their big products; exposed here for tests and tools.
 # --------------------------------------------------------------------------------------------------
 class HpTensor:
-    """hp planes of an fp32 matrix (rows x K): device byte buffer + the device amax word the scale derives from."""
+    """hp planes of an fp32 matrix (rows x K): device byte buffer + the per-row amax words the row scales derive from."""
 
     def __init__(self, rows: int, K: int, device):
         self.rows, self.K = int(rows), int(K)
         n = _lib.lib().rnnt_hip_hp_bytes(self.rows, self.K)
         self.planes = torch.empty(max(n, 128), device=device, dtype=torch.uint8)
-        self.amax = torch.zeros(1, device=device, dtype=torch.int32)
+        self.amax = torch.zeros(max(self.rows, 1), device=device, dtype=torch.int32)   # per-row maxima (fp32 bit patterns)
 
 
 def hp_split(x: torch.Tensor, transpose: bool = False, shift: int = 0, K: Optional[int] = None) -> HpTensor:

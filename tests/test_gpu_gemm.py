@@ -209,7 +209,7 @@ def test_gemm_hp_matches_fp64(M, N, K):
     out2 = base.clone().cuda()
     gemm_hp(hp_split(A.cuda()), hp_split(W.cuda()), out=out2, bias=bias.cuda(), accumulate=True)
     ref2 = ref + bias.double() + base.double()
-    assert ((out2.double().cpu() - ref2).abs() / (scale + ref2.abs())).max().item() < 2e-6
+    assert ((out2.double().cpu() - ref2).abs() / (scale + bias.abs().double() + base.abs().double())).max().item() < 2e-6
 
 
 def test_gemm_hp_transposed_and_shifted_operands_split_k():
