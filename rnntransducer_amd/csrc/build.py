@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 INCLUDE = os.path.join(ROOT, "include")
-SOURCES = ["api.hip", "gemm.hip", "gemm_hp.hip", "loss.hip", "lstm.hip", "decode.hip", "frontend.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_hp.hip", "loss.hip", "lstm.hip", "lstm5.hip", "decode.hip", "frontend.hip"]
 LIB = os.path.join(HERE, "librnnt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + HERE, "-Wno-unused-result"]
@@ -21,7 +21,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.hpp"),
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "lstm_shared.hpp"),
                                                          os.path.join(INCLUDE, "rnnt_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

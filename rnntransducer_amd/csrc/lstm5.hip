@@ -1,0 +1,312 @@
+// v5 persistent recurrences: tagged-payload exchange (no flag round), f16 matrix cores on half-pair operands.
+//
+// Same decomposition as lstm.hip's v3 / v4 register forms — sync groups = direction x batch slice (<= 16 rows), a workgroup owns
+// 16 hidden units (64 gate columns), W_hh stationary in registers, K split over the 4 waves — with two changes that cut the
+// per-timestep dependency chain (profiles/r01_lstm_phase_cycles_v3_v4.txt: 7.1 k cycles forward, of which 2.95 k were the
+// flag protocol and 1.5 k the six bf16 piece products):
+//
+//   1. The exchanged value IS the flag.  A hidden value travels as ONE dword = (hi fp16 | lo fp16 << 16) with the generation bit of
+//      its timestep in the lowest mantissa bit of lo; the producer's 4-byte store is the publication (no vmcnt drain, no workgroup
+//      barrier, no flag store) and a consumer wave polls exactly the 128 k x 16 rows it multiplies (8 producers), re-loading
+//      until every dword carries the expected generation.  One L2 round trip after the producer's store lands, instead of
+//      drain -> barrier -> flag -> poll -> barrier -> gather.  Buffers alternate by step parity; a slot is overwritten two steps later,
+//      which its producer can only reach after every consumer has published the step in between (data dependency = the old
+//      flag order), so a reader sees the wanted generation or the one two steps older, never a mix it cannot tell apart.
+//   2. h . W_hh^T on v_mfma_f32_16x16x32_f16 with half-pair operands (gemm_hp.hip's arithmetic): h in (-1, 1) scaled by 2^14,
+//      W_hh scaled by a power of two from the workgroup's own slice maximum; 3 products (lo.hi + hi.lo + hi.hi) instead of 6.
+//
+// Correctness never depends on placement: stores are sc1 write-through unless the group is VERIFIED to sit on one XCD (then
+// plain stores stay in that L2), loads are always sc1 (bypass L1).  All spins are bounded and raise the status word.
+#include "lstm_shared.hpp"
+
+namespace rnnt {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr unsigned TAG_MASK = 0x00010000u;   // lowest mantissa bit of the lo half
+
+__device__ __forceinline__ unsigned pack_hp(float v, unsigned tag) {
+  // v already scaled (|v| < 2^15): hi = fp16_rn(v), lo = fp16_rn(v - hi) with its last bit replaced by the generation tag
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  const unsigned h = (unsigned)__builtin_bit_cast(unsigned short, hi), l = (unsigned)__builtin_bit_cast(unsigned short, lo);
+  return h | ((l & 0xfffeu) << 16) | (tag << 16);
+}
+
+// 8 fp32 weights (consecutive k) -> hi / lo f16x8 fragments, scaled
+__device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, float scale, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = (e < 4 ? a[e] : b[e - 4]) * scale;
+    const _Float16 h = (_Float16)v;
+    hi[e] = h;
+    lo[e] = (_Float16)(v - (float)h);
+  }
+}
+
+// Waits until every lane's predicate holds (wave-level), re-running `load_and_check` (which (re)issues the lane's loads and returns
+// whether all its dwords carry the expected tag).  Bounded: gives up after SPIN_LIMIT_TICKS or when another workgroup raised the
+// status word, raising it itself.  Returns false on abort.
+template <typename F>
+__device__ __forceinline__ bool poll_tagged(F&& load_and_check, unsigned* status) {
+  if (__all(load_and_check())) return true;
+  const unsigned long long t0 = wall_clock64();
+  unsigned spins = 0;
+  while (true) {
+    __builtin_amdgcn_s_sleep(1);
+    if (__all(load_and_check())) return true;
+    if ((++spins & 63u) == 0u) {
+      const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (st != 0u || wall_clock64() - t0 > SPIN_LIMIT_TICKS) {
+        if ((threadIdx.x & 63) == 0 && st == 0u) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// forward.  dynamic LDS: part[2 parities][4 waves][4 blocks][64] f32x4 (32 KB) | wmax[4] | abort
+// NKS: 32-deep k-steps per wave (H = 128 * NKS).  CELL: 0 LSTM, 1 GRU, 2 tanh Elman RNN.
+// ================================================================================================
+template <int NKS, int CELL>
+__global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
+  constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
+  constexpr int MB = 4, HS = 16, Kw = 32 * NKS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* part = reinterpret_cast<f32x4*>(smem);
+  float* wmax = reinterpret_cast<float*>(part + 2 * 4 * MB * 64);
+  int* abort_lds = reinterpret_cast<int*>(wmax + 4);
+
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NG = D * p.G;
+  const int gid = blockIdx.x % p.NGL, wg = blockIdx.x / p.NGL;
+  if (gid >= NG) return;
+  const int d = gid / p.G, g = gid % p.G;
+  const int b0 = g * p.Bg, j0 = wg * HS;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  // W_hh slice: lane -> gate column 16*mb + lrow (gate lrow&3 of unit 4*mb + (lrow>>2)), k = wave*Kw + 32*ks + 8*lq + e
+  f16x8 whi[MB][NKS], wlo[MB][NKS];
+  float out_scale;
+  {
+    const float* W = p.w_hh[d];
+    const int gate = lrow & 3;
+    f32x4 raw[MB][NKS][2];
+    float m = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float* row = W + (long)(gate * H + j0 + 4 * mb + (lrow >> 2)) * H;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int k = wave * Kw + 32 * ks + 8 * lq;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (gate < NGATE) {
+          lo = *reinterpret_cast<const f32x4*>(row + k);
+          hi = *reinterpret_cast<const f32x4*>(row + k + 4);
+        }
+        raw[mb][ks][0] = lo;
+        raw[mb][ks][1] = hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) wmax[wave] = m;
+    if (tid == 0) *abort_lds = 0;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    // power-of-two scale bringing the slice maximum into [2^14, 2^15)
+    int eb = (int)((__float_as_uint(m) >> 23) & 255u);
+    eb = eb < 15 ? 15 : eb;
+    const float wscale = m > 0.f ? __uint_as_float((unsigned)(268 - eb) << 23) : 1.f;
+    out_scale = (m > 0.f ? __uint_as_float((unsigned)(eb - 14) << 23) : 1.f) * 6.103515625e-05f;  // / wscale / 2^14
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) split8h(raw[mb][ks][0], raw[mb][ks][1], wscale, whi[mb][ks], wlo[mb][ks]);
+  }
+
+  const int NBR = 4 * ((p.Bg + 3) / 4);  // exchange rows of the group (host allocation)
+  const long hx_bytes = (long)NBR * Kp * 4;  // one (parity, group) image: [row][Kp] packed dwords
+  __amdgpu_buffer_rsrc_t hx_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    hx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.hx) + ((long)par * NG + gid) * hx_bytes, 0, (int)hx_bytes,
+                                                     RSRC_FLAGS);
+
+  // one cell per lane: unit 4*wave + lq of this workgroup, batch row lrow of this group
+  const int brow = lrow;
+  const int ob = b0 + brow, oj = j0 + 4 * wave + lq;
+  const bool inrow = brow < NBR;
+  const bool valid = brow < p.Bg && ob < B;
+  const int olen = valid ? p.lens[ob] : 0;
+  float c_state = 0.f;
+  const float bhn = CELL == 1 ? p.b_hh[d][2 * H + oj] : 0.f;
+  const int t_first = (d == 0) ? 0 : T - 1;
+  const long tdir = (d == 0) ? 1 : -1;
+  long g_off = (((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj;
+  long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3);
+  long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
+  const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
+  const int hx_off = (brow * Kp + oj) * 4;
+  const int gat_off = inrow ? (brow * Kp + wave * Kw + 8 * lq) * 4 : 0x7ffffff0;  // rows beyond the group read 0 and are not checked
+  unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
+  const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
+
+  auto run = [&](auto local_tag) -> bool {
+  constexpr bool LOCAL = decltype(local_tag)::value;
+  for (int s = 0; s < T; ++s) {
+    const int t = (d == 0) ? s : T - 1 - s;
+    f32x4 xp = {0.f, 0.f, 0.f, 0.f};
+    if (valid) xp = *reinterpret_cast<const f32x4*>(p.gates + g_off);
+
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    DBG_STAMP(0);
+    bool ok = true;
+    if (s > 0) {
+      const __amdgpu_buffer_rsrc_t src = hx_rsrc[(s - 1) & 1];
+      const unsigned want = ((((unsigned)(s - 1) >> 1) & 1u) ^ 1u) << 16;
+      u32x4 raw[NKS][2];
+      ok = poll_tagged([&]() -> bool {
+        unsigned bad = 0;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          raw[ks][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, gat_off + 128 * ks, 0, AUX_SC1));
+          raw[ks][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, gat_off + 128 * ks + 16, 0, AUX_SC1));
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bad |= (raw[ks][0][e] ^ want) | (raw[ks][1][e] ^ want);
+        return !inrow || (bad & TAG_MASK) == 0u;
+      }, p.status);
+      DBG_STAMP(1);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        // de-interleave 8 packed dwords into the hi / lo operand fragments (k order kept), tag bit cleared
+        u32x4 h4, l4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned d0 = j < 2 ? raw[ks][0][2 * j] : raw[ks][1][2 * j - 4], d1 = j < 2 ? raw[ks][0][2 * j + 1] : raw[ks][1][2 * j - 3];
+          h4[j] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);                    // {d1.lo16, d0.lo16}
+          l4[j] = __builtin_amdgcn_perm(d1, d0, 0x07060302u) & 0xfffefffeu;      // {d1.hi16, d0.hi16}
+        }
+        const f16x8 hh = __builtin_bit_cast(f16x8, h4), hl = __builtin_bit_cast(f16x8, l4);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[mb][ks], hh, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[mb][ks], hl, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[mb][ks], hh, acc[mb], 0, 0, 0);
+        }
+      }
+      DBG_STAMP(2);
+    }
+    if (!ok) *abort_lds = 1;   // benign race: any wave that gave up makes the whole workgroup leave after the barrier
+    f32x4* pp = part + (s & 1) * (4 * MB * 64);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      if (mb != wave) pp[(wave * MB + mb) * 64 + lane] = acc[mb];
+    __syncthreads();
+    if (*abort_lds != 0) return false;
+    f32x4 rec = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      if (mb == wave) rec = acc[mb];   // own block stays in registers
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (w != wave) rec += pp[(w * MB + wave) * 64 + lane];
+    rec *= out_scale;
+    const bool active = valid && t < olen;
+    float hval = 0.f;
+    f32x4 gact = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      if constexpr (CELL == 0) {
+        const f32x4 g4 = xp + rec;
+        const float ig = sig_sel(g4[0], p.hw_math), fg = sig_sel(g4[1], p.hw_math), gg = tanh_sel(g4[2], p.hw_math), og = sig_sel(g4[3], p.hw_math);
+        c_state = fg * c_state + ig * gg;
+        hval = og * tanh_sel(c_state, p.hw_math);
+        gact = (f32x4){ig, fg, gg, og};
+      } else if constexpr (CELL == 1) {
+        const float rg = sig_sel(xp[0] + rec[0], p.hw_math), zg = sig_sel(xp[1] + rec[1], p.hw_math);
+        const float hn = rec[2] + bhn;
+        const float ng = tanh_sel(xp[2] + rg * hn, p.hw_math);
+        hval = (1.f - zg) * ng + zg * c_state;
+        c_state = hval;
+        gact = (f32x4){rg, zg, ng, hn};
+      } else {
+        hval = tanh_sel(xp[0] + rec[0], p.hw_math);
+        c_state = hval;
+        gact = (f32x4){hval, 0.f, 0.f, 0.f};
+      }
+    } else {
+      c_state = 0.f;
+    }
+    if (inrow) {  // the publication: ONE dword = (hi | lo << 16) of h * 2^14, generation bit in lo's last mantissa bit
+      const unsigned tag = (((unsigned)s >> 1) & 1u) ^ 1u;
+      const int v = (int)pack_hp(hval * 16384.f, tag);
+      if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(v, hx_rsrc[s & 1], hx_off, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b32(v, hx_rsrc[s & 1], hx_off, 0, AUX_SC1);
+    }
+    DBG_STAMP(3);
+    if (valid) {  // stash for the backward pass (and the layer output): never waited for inside the loop
+      *reinterpret_cast<f32x4*>(p.gates + g_off) = gact;
+      if constexpr (CELL == 0) p.cst[c_off] = c_state;
+      p.y[y_off] = hval;
+      if (p.ydrop)
+        p.ydrop[y_off] = (hash_u32(p.seed, (unsigned long long)y_off) >= p.drop_thresh) ? hval * p.keep_scale : 0.f;
+    }
+    g_off += g_step;
+    c_off += c_step;
+    y_off += y_step;
+    DBG_STAMP(5);
+  }
+  return true;
+  };
+  const bool okrun = local ? run(std::true_type{}) : run(std::false_type{});
+  if (!okrun) return;
+  if (p.dbg && tid == 0) {
+    for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    p.dbg[blockIdx.x * 8 + 6] = local ? 1 : 0;
+    p.dbg[blockIdx.x * 8 + 7] = xcc_id & 0xf;
+  }
+}
+
+}  // namespace
+
+// host side ----------------------------------------------------------------------------------------------------
+// v5 takes H in {128, 256, 384, 512} (4 waves, one k-quarter each), cells LSTM / GRU / tanh RNN; everything else stays on v3 / v4
+bool lstm5_supported(int H, int cell) {
+  if (getenv("RNNT_LSTM_NO_V5") || getenv("RNNT_LSTM_V1") || getenv("RNNT_LSTM_V2")) return false;
+  return H % 128 == 0 && H >= 128 && H <= 512 && cell != RNNT_CELL_RNN_RELU;
+}
+
+size_t lstm5_fwd_lds() { return (size_t)2 * 4 * 4 * 64 * 16 + 16 + 16; }
+
+int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
+  const size_t lds = lstm5_fwd_lds();
+  const int nks = k.Kp / 128;
+  int rc = RNNT_ERR_UNSUPPORTED;
+#define L5(N)                                                                                              \
+  do {                                                                                                     \
+    if (cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd5_kernel<N, 0>, k, pl, lds, s, "lstm_fwd5");      \
+    else if (cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd5_kernel<N, 1>, k, pl, lds, s, "lstm_fwd5");  \
+    else rc = launch_persistent2(lstm_fwd5_kernel<N, 2>, k, pl, lds, s, "lstm_fwd5");                      \
+  } while (0)
+  if (nks == 1) L5(1);
+  else if (nks == 2) L5(2);
+  else if (nks == 3) L5(3);
+  else if (nks == 4) L5(4);
+  else set_error("lstm_fwd5: H = %d not supported", k.H);
+#undef L5
+  return rc;
+}
+
+}  // namespace rnnt
