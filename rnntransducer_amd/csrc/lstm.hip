@@ -1751,7 +1751,7 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
       else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1>, k, p2, p2.lds_fwd, s, "lstm_fwd3"); \
       else rc = launch_persistent2(lstm_fwd3_kernel<N, 2>, k, p2, p2.lds_fwd, s, "lstm_fwd3");                     \
     } while (0)
-    if (p2.MB == 4 && nks <= 4 && lstm5_supported(d->H, d->cell)) {  // v5: tagged-payload exchange, f16 matrix cores (lstm5.hip)
+    if (p2.MB == 4 && nks <= 4 && lstm5_supported(d->T, d->B, d->H, d->D, d->cell)) {  // v5: tagged-payload exchange, f16 matrix cores (lstm5.hip)
       rc = lstm5_fwd_launch(k, p2, d->cell, s);
     } else if (p2.MB == 5) {  // H = 640: 5 blocks, 8 waves x 3 k-steps over K padded to 768
       const size_t lds5 = p2.lds_fwd + 8 * 1 * 3 * 3 * 1024;  // one of the five blocks' pieces in LDS

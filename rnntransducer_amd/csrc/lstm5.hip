@@ -78,9 +78,11 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
   f32x4* part = reinterpret_cast<f32x4*>(smem);
   float* wmax = reinterpret_cast<float*>(part + 2 * 4 * MB * 64);
   int* abort_lds = reinterpret_cast<int*>(wmax + 4);
+  unsigned* pubs = reinterpret_cast<unsigned*>(abort_lds + 4);   // [16 rows][16 units] packed dwords (write-through path only)
 
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the per-wave role tests below become scalar branches
   const int NG = D * p.G;
   const int gid = blockIdx.x % p.NGL, wg = blockIdx.x / p.NGL;
   if (gid >= NG) return;
@@ -146,46 +148,58 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
   const int olen = valid ? p.lens[ob] : 0;
   float c_state = 0.f;
   const float bhn = CELL == 1 ? p.b_hh[d][2 * H + oj] : 0.f;
+  // stash / prefetch through buffer resources with per-lane byte offsets: inactive lanes carry an out-of-range offset (loads
+  // return 0, stores are dropped), so the loop body has NO divergent branch around a memory operation and hipcc can count
+  // exactly how many younger operations may stay in flight when it waits for the gathered operands (a vmcnt(0) there would also
+  // wait for this step's stash stores)
+  constexpr int OOB = 0x7ffffff0;
   const int t_first = (d == 0) ? 0 : T - 1;
-  const long tdir = (d == 0) ? 1 : -1;
-  long g_off = (((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj;
-  long c_off = ((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3);
-  long y_off = (((long)t_first * B + ob) * D + d) * H + oj;
-  const long g_step = tdir * (long)B * D * 4 * H, c_step = tdir * (long)H * B, y_step = tdir * (long)B * D * H;
-  const int hx_off = (brow * Kp + oj) * 4;
+  const int tdir = (d == 0) ? 1 : -1;
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)T * B * D * 4 * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * T * B * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t yd_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ydrop, 0, p.ydrop ? (int)((long)T * B * D * H * 4) : 0, RSRC_FLAGS);
+  int g_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj) * 4) : OOB;
+  int c_off = valid ? (int)((((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
+  int y_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * H + oj) * 4) : OOB;
+  const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
+  const int hx_off = inrow ? (brow * Kp + oj) * 4 : OOB;
   const int gat_off = inrow ? (brow * Kp + wave * Kw + 8 * lq) * 4 : 0x7ffffff0;  // rows beyond the group read 0 and are not checked
   unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
   const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
 
   auto run = [&](auto local_tag) -> bool {
   constexpr bool LOCAL = decltype(local_tag)::value;
+  u32x4 raw[NKS][2];   // the next step's operand dwords: loads are issued right behind this step's publication
+  auto issue_gather = [&](int s_next) {
+    const __amdgpu_buffer_rsrc_t src = hx_rsrc[(s_next - 1) & 1];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      raw[ks][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, gat_off + 128 * ks, 0, AUX_SC1));
+      raw[ks][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, gat_off + 128 * ks + 16, 0, AUX_SC1));
+    }
+  };
+  auto tags_ok = [&](unsigned want) -> bool {
+    unsigned bad = 0;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bad |= (raw[ks][0][e] ^ want) | (raw[ks][1][e] ^ want);
+    return !inrow || (bad & TAG_MASK) == 0u;
+  };
+  f32x4 xp = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_off, 0, 0));
   for (int s = 0; s < T; ++s) {
     const int t = (d == 0) ? s : T - 1 - s;
-    f32x4 xp = {0.f, 0.f, 0.f, 0.f};
-    if (valid) xp = *reinterpret_cast<const f32x4*>(p.gates + g_off);
-
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     DBG_STAMP(0);
     bool ok = true;
     if (s > 0) {
-      const __amdgpu_buffer_rsrc_t src = hx_rsrc[(s - 1) & 1];
       const unsigned want = ((((unsigned)(s - 1) >> 1) & 1u) ^ 1u) << 16;
-      u32x4 raw[NKS][2];
-      ok = poll_tagged([&]() -> bool {
-        unsigned bad = 0;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          raw[ks][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, gat_off + 128 * ks, 0, AUX_SC1));
-          raw[ks][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, gat_off + 128 * ks + 16, 0, AUX_SC1));
-        }
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bad |= (raw[ks][0][e] ^ want) | (raw[ks][1][e] ^ want);
-        return !inrow || (bad & TAG_MASK) == 0u;
-      }, p.status);
+      if (!__all(tags_ok(want))) {   // first round was issued behind the previous step's publication
+        ok = poll_tagged([&]() -> bool { issue_gather(s); return tags_ok(want); }, p.status);
+      }
       DBG_STAMP(1);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -210,17 +224,11 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
     if (!ok) *abort_lds = 1;   // benign race: any wave that gave up makes the whole workgroup leave after the barrier
     f32x4* pp = part + (s & 1) * (4 * MB * 64);
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-      if (mb != wave) pp[(wave * MB + mb) * 64 + lane] = acc[mb];
+    for (int mb = 0; mb < MB; ++mb) pp[(wave * MB + mb) * 64 + lane] = acc[mb];
     __syncthreads();
+    DBG_STAMP(3);   // partial write + barrier (includes the skew between this workgroup's waves)
     if (*abort_lds != 0) return false;
-    f32x4 rec = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-      if (mb == wave) rec = acc[mb];   // own block stays in registers
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-      if (w != wave) rec += pp[(w * MB + wave) * 64 + lane];
+    f32x4 rec = (pp[(0 * MB + wave) * 64 + lane] + pp[(1 * MB + wave) * 64 + lane]) + (pp[(2 * MB + wave) * 64 + lane] + pp[(3 * MB + wave) * 64 + lane]);
     rec *= out_scale;
     const bool active = valid && t < olen;
     float hval = 0.f;
@@ -228,42 +236,58 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
     if (active) {
       if constexpr (CELL == 0) {
         const f32x4 g4 = xp + rec;
-        const float ig = sig_sel(g4[0], p.hw_math), fg = sig_sel(g4[1], p.hw_math), gg = tanh_sel(g4[2], p.hw_math), og = sig_sel(g4[3], p.hw_math);
+        const float ig = sigmoid_hw(g4[0]), fg = sigmoid_hw(g4[1]), gg = tanh_hw(g4[2]), og = sigmoid_hw(g4[3]);
         c_state = fg * c_state + ig * gg;
-        hval = og * tanh_sel(c_state, p.hw_math);
+        hval = og * tanh_hw(c_state);
         gact = (f32x4){ig, fg, gg, og};
       } else if constexpr (CELL == 1) {
-        const float rg = sig_sel(xp[0] + rec[0], p.hw_math), zg = sig_sel(xp[1] + rec[1], p.hw_math);
+        const float rg = sigmoid_hw(xp[0] + rec[0]), zg = sigmoid_hw(xp[1] + rec[1]);
         const float hn = rec[2] + bhn;
-        const float ng = tanh_sel(xp[2] + rg * hn, p.hw_math);
+        const float ng = tanh_hw(xp[2] + rg * hn);
         hval = (1.f - zg) * ng + zg * c_state;
         c_state = hval;
         gact = (f32x4){rg, zg, ng, hn};
       } else {
-        hval = tanh_sel(xp[0] + rec[0], p.hw_math);
+        hval = tanh_hw(xp[0] + rec[0]);
         c_state = hval;
         gact = (f32x4){hval, 0.f, 0.f, 0.f};
       }
     } else {
       c_state = 0.f;
     }
-    if (inrow) {  // the publication: ONE dword = (hi | lo << 16) of h * 2^14, generation bit in lo's last mantissa bit
+    {  // the publication: ONE dword = (hi | lo << 16) of h * 2^14, generation bit in lo's last mantissa bit
       const unsigned tag = (((unsigned)s >> 1) & 1u) ^ 1u;
       const int v = (int)pack_hp(hval * 16384.f, tag);
-      if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(v, hx_rsrc[s & 1], hx_off, 0, 0);
-      else __builtin_amdgcn_raw_buffer_store_b32(v, hx_rsrc[s & 1], hx_off, 0, AUX_SC1);
+      if constexpr (LOCAL) {
+        __builtin_amdgcn_raw_buffer_store_b32(v, hx_rsrc[s & 1], hx_off, 0, 0);   // stays in the group's L2
+      } else {
+        // group spans XCDs: write-through stores, and a 4-byte sc1 store is one fabric write each (12x the time per byte of a
+        // 16-byte one): gather the workgroup's 16 rows x 16 units in LDS and let wave 0 store 64 granules of 16 bytes
+        pubs[brow * 16 + 4 * wave + lq] = (unsigned)v;
+        __syncthreads();
+        if (wave == 0) {
+          const i32x4 gran = *reinterpret_cast<const i32x4*>(pubs + lrow * 16 + 4 * lq);
+          __builtin_amdgcn_raw_buffer_store_b128(gran, hx_rsrc[s & 1], lrow < NBR ? (lrow * Kp + j0 + 4 * lq) * 4 : OOB, 0, AUX_SC1);
+        }
+      }
     }
-    DBG_STAMP(3);
-    if (valid) {  // stash for the backward pass (and the layer output): never waited for inside the loop
-      *reinterpret_cast<f32x4*>(p.gates + g_off) = gact;
-      if constexpr (CELL == 0) p.cst[c_off] = c_state;
-      p.y[y_off] = hval;
-      if (p.ydrop)
-        p.ydrop[y_off] = (hash_u32(p.seed, (unsigned long long)y_off) >= p.drop_thresh) ? hval * p.keep_scale : 0.f;
+    DBG_STAMP(4);   // reduce + cell math + publication
+    issue_gather(s + 1);   // first poll round of the next step, in flight under the stash stores below (unused after the last step)
+    // next step's gate pre-activations BEFORE the stash stores: memory operations retire in issue order, so a wait for this load
+    // (or for the gathered operands) never waits for the stores behind it
+    const f32x4 xp_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
+    // stash for the backward pass (and the layer output): not waited for until the NEXT step's operands are waited for
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gact), g_rsrc, g_off, 0, 0);
+    if constexpr (CELL == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c_state), c_rsrc, c_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hval), y_rsrc, y_off, 0, 0);
+    if (p.ydrop) {
+      const float hd = (hash_u32(p.seed, (unsigned long long)(unsigned)(y_off >> 2)) >= p.drop_thresh) ? hval * p.keep_scale : 0.f;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hd), yd_rsrc, y_off, 0, 0);
     }
     g_off += g_step;
     c_off += c_step;
     y_off += y_step;
+    xp = xp_next;
     DBG_STAMP(5);
   }
   return true;
@@ -283,12 +307,13 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
 
 // host side ----------------------------------------------------------------------------------------------------
 // v5 takes H in {128, 256, 384, 512} (4 waves, one k-quarter each), cells LSTM / GRU / tanh RNN; everything else stays on v3 / v4
-bool lstm5_supported(int H, int cell) {
-  if (getenv("RNNT_LSTM_NO_V5") || getenv("RNNT_LSTM_V1") || getenv("RNNT_LSTM_V2")) return false;
+bool lstm5_supported(int T, int B, int H, int D, int cell) {
+  if (getenv("RNNT_LSTM_NO_V5") || getenv("RNNT_LSTM_V1") || getenv("RNNT_LSTM_V2") || getenv("RNNT_LSTM_EXACT_MATH")) return false;
+  if ((long)T * B * D * 4 * H * 4 >= (1l << 31)) return false;   // the stash is addressed with 32-bit buffer offsets
   return H % 128 == 0 && H >= 128 && H <= 512 && cell != RNNT_CELL_RNN_RELU;
 }
 
-size_t lstm5_fwd_lds() { return (size_t)2 * 4 * 4 * 64 * 16 + 16 + 16; }
+size_t lstm5_fwd_lds() { return (size_t)2 * 4 * 4 * 64 * 16 + 16 + 16 + 1024; }
 
 int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
   const size_t lds = lstm5_fwd_lds();

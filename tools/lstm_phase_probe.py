@@ -15,6 +15,8 @@ lstm = HipLSTM(I, H, 1, bidirectional=True).cuda()
 x = torch.randn(T, B, I, device="cuda", requires_grad=True)
 lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
 names = ["prefetch issue", "flag wait", "gather+MFMA", "reduce+cell math", "drain+barrier+flag", "stash stores"]
+names5 = ["loop top", "tagged poll (wait for operands)", "de-interleave + MFMA", "partial write + barrier", "reduce + cell math + publish",
+          "gather issue + stash + prefetch"]
 
 class Hook:
     pass
@@ -25,7 +27,8 @@ def read(ws, tag):
     tot = out[:, :6].sum(1).astype(np.float64)
     print(f"--- {tag}: cycles/step per phase (median over 256 workgroups; min..max), total {np.median(tot) / T:.0f} cyc/step")
     print(f"   xcd-local groups: {int(out[:, 6].sum())}/256 workgroups; XCC ids of blocks 0..15: {out[:16, 7].astype(int).tolist()}")
-    for i, n in enumerate(names):
+    v5 = tag == "forward" and not os.environ.get("RNNT_LSTM_NO_V5")
+    for i, n in enumerate(names5 if v5 else names):
         v = out[:, i].astype(np.float64) / T
         print(f"   {n:22s} {np.median(v):8.0f}   ({v.min():.0f} .. {v.max():.0f})")
 
