@@ -1848,7 +1848,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       else if (d->cell == RNNT_CELL_GRU) LAUNCH_V4_B(N, 1);        \
       else LAUNCH_V4_B(N, 2);                                      \
     } while (0)
-    if (p2.MB == 5) {  // H = 640: own 80 gate columns (3 k-steps), 48 output blocks over 8 waves
+    if (p2.MB == 4 && nks <= 4 && lstm5_supported(d->T, d->B, d->H, d->D, d->cell)) {  // v5 (lstm5.hip)
+      rc = lstm5_bwd_launch(k, p2, d->cell, s);
+    } else if (p2.MB == 5) {  // H = 640: own 80 gate columns (3 k-steps), 48 output blocks over 8 waves
 #define LAUNCH_V45_C(BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<6, BQ_, C, 8, 5, 1>, k, p2, p2.lds_bwd + 8 * 1 * 3 * 3 * 1024, s, "lstm_bwd4", 512)
 #define LAUNCH_V45_B(C)                           \
       do {                                        \

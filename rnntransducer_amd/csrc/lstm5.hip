@@ -303,6 +303,299 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
   }
 }
 
+
+// ================================================================================================
+// backward ("scatter form" of lstm.hip's v4 with the v5 exchange and arithmetic).
+//   A workgroup multiplies ITS OWN 64 gate columns of dG_t (16 rows x 64, produced by its own cell math) by its 64 rows of
+//   W_hh and publishes the partial dh_{t-1} for ALL hidden units; a consumer sums, for its 16 units, the NC partial slices.
+//   Exchange: fp32 partial sums as 16-byte granules (4 units of one row), stored by ONE lane straight from the MFMA output
+//   registers, generation bit in the last mantissa bit of elements 0 and 2 (one per 8-byte half); a gathering thread re-loads
+//   a granule until both halves carry the wanted generation.  No flag, no drain, no publication barrier.
+//   Arithmetic: dG rows scaled per (row, workgroup) by a power of two from the row's maximum over the 64 own columns (LDS
+//   ds_max), W_hh by the slice maximum; 3 f16 products; the product is descaled before it is published.
+// dynamic LDS: red[256] f32x4 | dgs[16][DGS_LD] float | rowexp[2][16] | wmax[4] | abort
+// ================================================================================================
+template <int NKS, int BQ, int CELL>
+__global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
+  constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
+  constexpr int HS = 16, UQ = 4, NT = 256;
+  constexpr int NMB = 2 * NKS;          // 16-unit output blocks per wave (H / 16 / 4)
+  constexpr int KSB = 2;                // 32-deep k-steps over the 64 own gate columns
+  constexpr int NBR = 4 * BQ;           // exchange rows of the group
+  constexpr int DGS_LD = 32 * KSB + 4;
+  constexpr int OOB = 0x7ffffff0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  float* dgs = reinterpret_cast<float*>(red + NT);
+  unsigned* rowexp = reinterpret_cast<unsigned*>(dgs + 16 * DGS_LD);
+  float* wmax = reinterpret_cast<float*>(rowexp + 32);
+  int* abort_lds = reinterpret_cast<int*>(wmax + 4);
+
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NG = D * p.G;
+  const int gid = blockIdx.x % p.NGL, wg = blockIdx.x / p.NGL;
+  if (gid >= NG) return;
+  const int d = gid / p.G, g = gid % p.G;
+  const int b0 = g * p.Bg, j0 = wg * HS;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  // W_hh slice as the A operand: lane -> output unit u = 16*(wave*NMB + mb) + lrow (a COLUMN of W_hh),
+  // k = 32*ks + 8*lq + e = own gate column 4*unit + gate  ->  W_hh[gate*H + j0 + (k>>2)][u]
+  f16x8 whi[NMB][KSB], wlo[NMB][KSB];
+  float w_inv;
+  {
+    const float* W = p.w_hh[d];
+    f32x4 raw[NMB][KSB][2];
+    float m = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const int u = 16 * (wave * NMB + mb) + lrow;
+#pragma unroll
+      for (int ks = 0; ks < KSB; ++ks) {
+        const int c = 32 * ks + 8 * lq;   // own gate column, a multiple of 8: units c>>2 and (c>>2)+1, gates 0..3 each
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (e < NGATE) {
+            lo[e] = W[(long)(e * H + j0 + (c >> 2)) * H + u];
+            hi[e] = W[(long)(e * H + j0 + (c >> 2) + 1) * H + u];
+          }
+        }
+        raw[mb][ks][0] = lo;
+        raw[mb][ks][1] = hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) wmax[wave] = m;
+    if (tid == 0) *abort_lds = 0;
+    if (tid < 32) rowexp[tid] = 0u;
+    for (int i = tid; i < 16 * DGS_LD; i += NT) dgs[i] = 0.f;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    int eb = (int)((__float_as_uint(m) >> 23) & 255u);
+    eb = eb < 15 ? 15 : eb;
+    const float wscale = m > 0.f ? __uint_as_float((unsigned)(268 - eb) << 23) : 1.f;
+    w_inv = m > 0.f ? __uint_as_float((unsigned)(eb - 14) << 23) : 1.f;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < KSB; ++ks) split8h(raw[mb][ks][0], raw[mb][ks][1], wscale, whi[mb][ks], wlo[mb][ks]);
+  }
+
+  const long px_bytes = (long)p.NC * NBR * Kp * 4;  // one (parity, group) image: [producer][row][Kp] fp32
+  __amdgpu_buffer_rsrc_t px_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    px_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.hx) + ((long)par * NG + gid) * px_bytes, 0, (int)px_bytes, RSRC_FLAGS);
+
+  // cell owners: tid = ((obq*UQ + uq)*4 + i)*4 + j -> unit j0 + 4*uq + i, batch row 4*obq + j
+  const bool owner = tid < BQ * HS * 4;
+  const int ojb = tid & 3, oi = (tid >> 2) & 3, ouq = (tid >> 4) % UQ, obq = (tid >> 4) / UQ;
+  const int brow = 4 * obq + ojb, ob = b0 + brow, oj = j0 + 4 * ouq + oi;
+  const bool valid = owner && brow < p.Bg && ob < B;
+  const int olen = valid ? p.lens[ob] : 0;
+  float dc_carry = 0.f;
+  f32x4 db_acc = {0.f, 0.f, 0.f, 0.f}, dbh_acc = {0.f, 0.f, 0.f, 0.f};
+  const int t_first = (d == 0) ? T - 1 : 0;
+  const int tdir = (d == 0) ? -1 : 1;
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)T * B * D * 4 * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, CELL == 1 ? (int)((long)T * B * D * 4 * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * T * B * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
+  int g_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj) * 4) : OOB;
+  int c_off = valid ? (int)((((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
+  int y_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * H + oj) * 4) : OOB;
+  const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
+
+  // gather: thread -> (row, unit quad) pair gpr and producer class gq; it sums the partial slices of producers gq, gq + NQ, ...
+  constexpr int NPAIR = NBR * UQ, NQ = NT / NPAIR, NLD = (32 + NQ - 1) / NQ;   // NC <= 32
+  const int gq = tid / NPAIR, gpr = tid % NPAIR;
+  const int grow = gpr / UQ, guq = gpr % UQ;
+  const int gat_base = ((gq * NBR + grow) * Kp + j0 + 4 * guq) * 4;   // bytes; + NQ producers per visit
+  const int gat_step = NQ * NBR * Kp * 4;
+  // publish: lane -> row lrow, units 16*(wave*NMB + mb) + 4*lq .. +3
+  const int pub_base = lrow < NBR ? ((wg * NBR + lrow) * Kp + 16 * wave * NMB + 4 * lq) * 4 : OOB;
+  unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
+  const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
+
+  auto run = [&](auto local_tag) -> bool {
+  constexpr bool LOCAL = decltype(local_tag)::value;
+  u32x4 gr[NLD];
+  auto issue_gather = [&](int s_next) {   // partials published at step s_next - 1
+    const __amdgpu_buffer_rsrc_t src = px_rsrc[(s_next - 1) & 1];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const bool okp = gq + NQ * i < p.NC;
+      gr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, okp ? gat_base + i * gat_step : OOB, 0, AUX_SC1));
+    }
+  };
+  auto tags_ok = [&](unsigned want) -> bool {
+    unsigned bad = 0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (gq + NQ * i < p.NC) bad |= (gr[i][0] ^ want) | (gr[i][2] ^ want);
+    return (bad & 1u) == 0u;
+  };
+  // prefetch of step 0
+  f32x4 gt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_off, 0, 0));
+  float c_t = 0.f, c_p = 0.f;
+  if constexpr (CELL == 0) {
+    c_t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, c_off, 0, 0));
+    c_p = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, T > 1 ? c_off + c_step : OOB, 0, 0));
+  } else if constexpr (CELL == 1) {
+    c_p = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, T > 1 ? y_off + y_step : OOB, 0, 0));
+  }
+  float dyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, y_off, 0, 0));
+  for (int s = 0; s < T; ++s) {
+    const int t = (d == 0) ? T - 1 - s : s;
+    const bool active = valid && t < olen;
+    if (p.ydrop) dyv = (hash_u32(p.seed, (unsigned long long)(unsigned)(y_off >> 2)) >= p.drop_thresh) ? dyv * p.keep_scale : 0.f;
+    DBG_STAMP(0);
+    f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (s > 0) {
+      const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;
+      if (!__all(tags_ok(want))) ok = poll_tagged([&]() -> bool { issue_gather(s); return tags_ok(want); }, p.status);
+      DBG_STAMP(1);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        u32x4 v = gr[i];
+        v[0] &= ~1u;
+        v[2] &= ~1u;
+        gsum += __builtin_bit_cast(f32x4, v);   // producers beyond NC loaded zeros
+      }
+    }
+    if (!ok) *abort_lds = 1;
+    red[tid] = gsum;
+    __syncthreads();
+    if (*abort_lds != 0) return false;
+    DBG_STAMP(2);  // partial sums + barrier
+    f32x4 dg4 = {0.f, 0.f, 0.f, 0.f}, dgh4 = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+      float dh = active ? dyv : 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) dh += red[q * NPAIR + brow * UQ + ouq][oi];
+      if (active) {
+        if constexpr (CELL == 0) {
+          const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
+          const float tc = tanh_hw(c_t);
+          const float dc = dh * og * (1.f - tc * tc) + dc_carry;
+          dg4[0] = dc * gg * ig * (1.f - ig);
+          dg4[1] = dc * c_p * fg * (1.f - fg);
+          dg4[2] = dc * ig * (1.f - gg * gg);
+          dg4[3] = dh * tc * og * (1.f - og);
+          dc_carry = dc * fg;
+          dgh4 = dg4;
+        } else if constexpr (CELL == 1) {
+          const float rg = gt[0], zg = gt[1], ng = gt[2], hn = gt[3];
+          dh += dc_carry;
+          const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+          const float dz_pre = dh * (c_p - ng) * zg * (1.f - zg);
+          const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+          dg4 = (f32x4){dr_pre, dz_pre, dn_pre, 0.f};
+          dgh4 = (f32x4){dr_pre, dz_pre, dn_pre * rg, 0.f};
+          dc_carry = dh * zg;
+        } else {
+          const float hv = gt[0];
+          dg4 = (f32x4){dh * (1.f - hv * hv), 0.f, 0.f, 0.f};
+          dgh4 = dg4;
+        }
+      } else {
+        dc_carry = 0.f;
+      }
+      db_acc += dg4;
+      if constexpr (CELL == 1) dbh_acc += dgh4;
+      *reinterpret_cast<f32x4*>(&dgs[brow * DGS_LD + 4 * (4 * ouq + oi)]) = dgh4;  // own gate column 4*unit + gate
+      const float mx = fmaxf(fmaxf(fabsf(dgh4[0]), fabsf(dgh4[1])), fmaxf(fabsf(dgh4[2]), fabsf(dgh4[3])));
+      atomicMax(&rowexp[(s & 1) * 16 + brow], __float_as_uint(mx));   // LDS ds_max_u32: the row's maximum over the 64 own columns
+    }
+    if (tid < 16) rowexp[((s & 1) ^ 1) * 16 + tid] = 0u;   // the other parity, for the next step
+    __syncthreads();
+    DBG_STAMP(3);  // cell math
+    {
+      const unsigned rmax = rowexp[(s & 1) * 16 + lrow];
+      int eb = (int)((rmax >> 23) & 255u);
+      eb = eb < 15 ? 15 : eb;
+      const float gscale = rmax != 0u ? __uint_as_float((unsigned)(268 - eb) << 23) : 1.f;
+      const float ginv = (rmax != 0u ? __uint_as_float((unsigned)(eb - 14) << 23) : 1.f) * w_inv;
+      f16x8 ghi[KSB], glo[KSB];
+#pragma unroll
+      for (int ks = 0; ks < KSB; ++ks) {
+        const float* src = dgs + lrow * DGS_LD + 32 * ks + 8 * lq;
+        split8h(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), gscale, ghi[ks], glo[ks]);
+      }
+      const unsigned tag = (((unsigned)s >> 1) & 1u) ^ 1u;
+      // groups of 4 output blocks: 4 independent accumulators between dependent MFMAs
+      constexpr int GB = NMB % 4 == 0 ? 4 : 2;   // NMB is 2, 4, 6 or 8
+#pragma unroll
+      for (int mb0 = 0; mb0 < NMB; mb0 += GB) {
+        f32x4 acc[GB];
+#pragma unroll
+        for (int j = 0; j < GB; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+#pragma unroll
+          for (int j = 0; j < GB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[mb0 + j][ks], ghi[ks], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < GB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[mb0 + j][ks], glo[ks], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < GB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[mb0 + j][ks], ghi[ks], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+          u32x4 out = __builtin_bit_cast(u32x4, acc[j] * ginv);
+          out[0] = (out[0] & ~1u) | tag;
+          out[2] = (out[2] & ~1u) | tag;
+          if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + 64 * (mb0 + j), 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + 64 * (mb0 + j), 0, AUX_SC1);
+        }
+      }
+    }
+    DBG_STAMP(4);  // scale + MFMA + publication
+    issue_gather(s + 1);
+    // next step's stash reads BEFORE this step's stash store (memory operations retire in issue order)
+    const int gn = s + 1 < T ? g_off + g_step : OOB;
+    const f32x4 gt_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, gn, 0, 0));
+    float ct_n = 0.f, cp_n = 0.f;
+    if constexpr (CELL == 0) {
+      ct_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 1 < T ? c_off + c_step : OOB, 0, 0));
+      cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 2 < T ? c_off + 2 * c_step : OOB, 0, 0));
+    } else if constexpr (CELL == 1) {
+      cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, s + 2 < T ? y_off + 2 * y_step : OOB, 0, 0));
+    }
+    const float dy_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, s + 1 < T ? y_off + y_step : OOB, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dg4), g_rsrc, g_off, 0, 0);
+    if constexpr (CELL == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dgh4), a_rsrc, g_off, 0, 0);
+    g_off += g_step;
+    c_off += c_step;
+    y_off += y_step;
+    gt = gt_n; c_t = ct_n; c_p = cp_n; dyv = dy_n;
+    DBG_STAMP(5);  // gather issue + prefetch + stash
+  }
+  return true;
+  };
+  const bool okrun = local ? run(std::true_type{}) : run(std::false_type{});
+  if (!okrun) return;
+  if (owner) {  // one row of the (group, exchange row) table per cell row; summed over rows and groups by db_reduce_kernel
+    const long row = (long)gid * NBR + brow;
+    *reinterpret_cast<f32x4*>(p.dbp + row * 4 * H + 4 * oj) = db_acc;
+    if constexpr (CELL == 1) *reinterpret_cast<f32x4*>(p.dbhp + row * 4 * H + 4 * oj) = dbh_acc;
+  }
+  if (p.dbg && tid == 0) {
+    for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    p.dbg[blockIdx.x * 8 + 6] = local ? 1 : 0;
+    p.dbg[blockIdx.x * 8 + 7] = xcc_id & 0xf;
+  }
+}
+
 }  // namespace
 
 // host side ----------------------------------------------------------------------------------------------------
@@ -331,6 +624,36 @@ int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
   else if (nks == 4) L5(4);
   else set_error("lstm_fwd5: H = %d not supported", k.H);
 #undef L5
+  return rc;
+}
+
+size_t lstm5_bwd_lds() { return (size_t)256 * 16 + 16 * (32 * 2 + 4) * 4 + 32 * 4 + 16 + 16; }
+
+int lstm5_bwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
+  const size_t lds = lstm5_bwd_lds();
+  const int nks = k.Kp / 128;
+  int rc = RNNT_ERR_UNSUPPORTED;
+#define B5C(N, Q, C) rc = launch_persistent2(lstm_bwd5_kernel<N, Q, C>, k, pl, lds, s, "lstm_bwd5")
+#define B5Q(N, C)                       \
+  do {                                  \
+    if (pl.BQ == 1) B5C(N, 1, C);       \
+    else if (pl.BQ == 2) B5C(N, 2, C);  \
+    else B5C(N, 4, C);                  \
+  } while (0)
+#define B5(N)                                        \
+  do {                                               \
+    if (cell == RNNT_CELL_LSTM) B5Q(N, 0);           \
+    else if (cell == RNNT_CELL_GRU) B5Q(N, 1);       \
+    else B5Q(N, 2);                                  \
+  } while (0)
+  if (nks == 1) B5(1);
+  else if (nks == 2) B5(2);
+  else if (nks == 3) B5(3);
+  else if (nks == 4) B5(4);
+  else set_error("lstm_bwd5: H = %d not supported", k.H);
+#undef B5
+#undef B5Q
+#undef B5C
   return rc;
 }
 

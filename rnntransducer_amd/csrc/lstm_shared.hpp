@@ -47,6 +47,7 @@ struct Plan2 {
 // v5 recurrences (lstm5.hip)
 bool lstm5_supported(int T, int B, int H, int D, int cell);
 int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s);
+int lstm5_bwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s);
 
 namespace {
 
