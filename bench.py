@@ -254,39 +254,44 @@ def main():
         if cnt[i]:
             kernels[name] = {"launches": int(cnt[i]), "ms_total": round(ms[i], 3), "avg_us": round(1e3 * ms[i] / cnt[i], 2),
                              "work_per_launch": work[i] / cnt[i]}
-    # GEMM arithmetic (include/rnnt_hip.h): default = every fp32 operand split exactly into 3 bf16 pieces, the 6 piece products
-    # of fp32 weight on the bf16 matrix cores, fp32 accumulate; "f32" = the f32-input MFMA.  The roofline of the split form is
-    # the bf16 dense peak divided by the products one fp32 product costs.
+    # GEMM arithmetic (include/rnnt_hip.h).  The big products of the LSTM layers run on gemm_hp_kernel: fp32 operands as two
+    # fp16 pieces ("half pair", per-row power-of-two scale), 3 piece products on v_mfma_f32_16x16x32_f16, fp32 accumulate:
+    # roofline = f16 dense peak / 3.  Everything else runs on gemm.hip: default 3 bf16 pieces / 6 products (peak / 6),
+    # "f32" = the f32-input MFMA.
     gemm_mode = os.environ.get("RNNT_GEMM_MODE") or "bf16x6"
     nprod = {"bf16x6": 6, "bf16x3": 3}.get(gemm_mode, 1)
     gemm_name = "gemm_f32_kernel" if nprod == 1 else "gemm_bf16s_kernel"  # incl. its 256x256-tile form gemm_bf16s256_kernel
-    gemm_peak = PEAK_FP32_MFMA_TFLOPS if nprod == 1 else PEAK_BF16_MFMA_TFLOPS / nprod
-    if nprod > 1 and "gemm_f32_kernel" in kernels:  # the profiler's kind 0 is "the GEMM kernel", whichever form ran
+    gemm_peak = {gemm_name: PEAK_FP32_MFMA_TFLOPS if nprod == 1 else PEAK_BF16_MFMA_TFLOPS / nprod,
+                 "gemm_hp_kernel": PEAK_BF16_MFMA_TFLOPS / 3}
+    if nprod > 1 and "gemm_f32_kernel" in kernels:  # the profiler's kind 0 is "the gemm.hip kernel", whichever form ran
         kernels = {(gemm_name if k == "gemm_f32_kernel" else k): v for k, v in kernels.items()}
-    for name, kd_ in kernels.items():  # every kernel kind against its own roofline (GEMM: MFMA; the rest: HBM)
+    for name, kd_ in kernels.items():  # every kernel kind against its own roofline (GEMMs: MFMA; the rest: HBM)
         sec = kd_["ms_total"] / kd_["launches"] / 1e3
-        if name == gemm_name:
-            kd_["tflops"] = round(kd_["work_per_launch"] / sec / 1e12, 2)  # algorithmic 2MNK
-            kd_["frac_of_mfma_peak"] = round(kd_["tflops"] / gemm_peak, 4)
+        if name in gemm_peak:
+            kd_["tflops"] = round(kd_["work_per_launch"] / sec / 1e12, 2)  # algorithmic 2MNK, fp32-equivalent
+            kd_["frac_of_mfma_peak"] = round(kd_["tflops"] / gemm_peak[name], 4)
         else:
             kd_["gbs"] = round(kd_["work_per_launch"] / sec / 1e9, 1)
             kd_["frac_of_hbm_peak"] = round(kd_["gbs"] / PEAK_HBM_GBS, 5)
         kd_["ms_per_step"] = round(kd_["ms_total"] / a.steps, 3)
-    dom = max((k for k in kernels if k != "misc"), key=lambda k: kernels[k]["ms_total"])
+    dom = max((k for k in kernels if k not in ("misc", "hp_split_kernels")), key=lambda k: kernels[k]["ms_total"])
     kd = kernels[dom]
     per_launch_s = kd["ms_total"] / kd["launches"] / 1e3
-    if dom == gemm_name:
+    if dom in gemm_peak:
         achieved = kd["work_per_launch"] / per_launch_s / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(gemm_peak, 1),
-                "unit": "TFLOP/s", "frac": round(achieved / gemm_peak, 4), "traffic": None}
-        if nprod > 1:
-            roof["note"] = (f"fp32 GEMM as {nprod} bf16 piece products per fp32 product (v_mfma_f32_32x32x16_bf16, fp32 accumulate): "
-                            f"peak = {PEAK_BF16_MFMA_TFLOPS:.0f} bf16 dense / {nprod}; issued {achieved * nprod:.0f} bf16 TFLOP/s; "
-                            f"the f32-input MFMA peak is {PEAK_FP32_MFMA_TFLOPS} (RNNT_GEMM_MODE=f32 runs on it)")
+        roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(gemm_peak[dom], 1),
+                "unit": "TFLOP/s", "frac": round(achieved / gemm_peak[dom], 4), "traffic": None}
+        roof["note"] = ("fp32-equivalent FLOP/s; peak = 2500 dense f16/bf16 MFMA TFLOP/s divided by the MFMA products one fp32 product "
+                        "costs (3 on half-pair f16 operands, 6 on bf16 pieces); the f32-input MFMA peak is 157.3")
     else:
         achieved = kd["work_per_launch"] / per_launch_s / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None}
+        if dom.startswith("lstm_"):
+            steps_per_launch = T
+            roof["note"] = (f"persistent recurrence: {T} dependent timesteps per launch, {1e6 * per_launch_s / steps_per_launch:.2f} us per "
+                            "timestep; bounded by the per-step exchange (one L2 hand-off) + 48 MFMAs + cell math chain, not by HBM: "
+                            "algorithmic bytes/launch = gates r+w, c, y or dy per (t,b,d) + weights (DESIGN.md section 4)")
     # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
     # MI355X_MICROARCH.md prescribes); collected offline because counters cannot be read from inside the process
     try:
@@ -302,8 +307,10 @@ def main():
     out = {
         "metric": "utterances/sec", "value": round(world * B * a.steps / dt, 3), "unit": "utt/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "gemm_arithmetic": gemm_mode,
-        "recurrence_arithmetic": "f32 MFMA (v2 kernels)" if os.environ.get("RNNT_LSTM_V2") else "bf16x6 (exact 3-way operand split, 6 products, fp32 accumulate)",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "gemm_arithmetic": ("f16x3 half-pair operands (LSTM input projection, dX, dW_ih, dW_hh) + " if not os.environ.get("RNNT_GEMM_NO_HP") else "") + gemm_mode,
+        "recurrence_arithmetic": "f32 MFMA (v2 kernels)" if os.environ.get("RNNT_LSTM_V2") else
+                                 ("bf16x6 (v3/v4)" if os.environ.get("RNNT_LSTM_NO_V5") else "f16x3 half-pair operands, fp32 accumulate (v5; H > 512: bf16x6 v3/v4)"),
         "data": "synthetic",
         "config": {"workload": f"{'BASELINE configs[%d]' % (list(CONFIGS).index(a.config) + (1 if a.config == 'c5' else 0)) if a.config != 'shipped' else 'reference config.json'} {a.config}: full train step, B={B}/GPU T={T} "
                                f"(10 ms frames x 80 mel) U={U} V={V}, enc {cfg[4][1]}x{cfg[4][0]} bi-{tn['rnn_type'].upper()}, pred {cfg[5][1]}x{cfg[5][0]} {pn['rnn_type'].upper()}, "

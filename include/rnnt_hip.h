@@ -43,7 +43,7 @@ int rnnt_hip_device_cus(void);
  * Opt-in live profiler (used by bench.py only).  While enabled, every kernel launch below is bracketed by two
  * HIP events recorded on the launch stream; collect() synchronises on them, sums elapsed ms / algorithmic work /
  * launch counts per kernel kind, and resets.  This is the only global state in the library, off by default.
- * `work` unit: FLOPs for RNNT_K_GEMM, algorithmic bytes for all other kinds.
+ * `work` unit: FLOPs for RNNT_K_GEMM and RNNT_K_GEMM_HP, algorithmic bytes for all other kinds.
  * ---------------------------------------------------------------------------------------------- */
 enum {
   RNNT_K_GEMM = 0,       /* gemm_f32_kernel                                   */
@@ -53,7 +53,9 @@ enum {
   RNNT_K_ALPHABETA = 4,  /* alphabeta_kernel                                  */
   RNNT_K_LATGRAD = 5,    /* grad_sep_kernel / grad_dense_kernel + reduce_dc   */
   RNNT_K_MISC = 6,       /* permutes, column sums, embedding, logits          */
-  RNNT_K_COUNT = 7
+  RNNT_K_GEMM_HP = 7,    /* gemm_hp_kernel (half-pair operands, f16 MFMA)     */
+  RNNT_K_HP_SPLIT = 8,   /* fp32 -> half-pair operand conversion passes       */
+  RNNT_K_COUNT = 9
 };
 int rnnt_hip_prof_enable(int on);
 int rnnt_hip_prof_collect(double* ms, double* work, int64_t* count, int nkinds);

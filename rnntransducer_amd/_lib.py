@@ -112,7 +112,7 @@ SYMBOLS = {
 }
 
 KERNEL_KINDS = ["gemm_f32_kernel", "lstm_fwd_kernel", "lstm_bwd_kernel", "lse_kernel", "alphabeta_kernel",
-                "lattice_grad_kernel", "misc"]
+                "lattice_grad_kernel", "misc", "gemm_hp_kernel", "hp_split_kernels"]
 
 _lib = None
 

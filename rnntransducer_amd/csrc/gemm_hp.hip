@@ -317,6 +317,129 @@ __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256 x 128 x 32 tile, 8 waves as 4 (M) x 2 (N), 64 x 64 of C per wave (4 x 4 blocks, 48 MFMAs per K-tile), THREE 48 KB LDS stages:
+// the LDS-DMA of K-tile t+2 is issued before tile t is multiplied and is only waited for (counted vmcnt, raw s_barrier: a
+// __syncthreads() would drain it) at the end of tile t+1 — two tiles of MFMA time to land instead of one.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int HP3_BM = 256, HP3_BN = 128, HP3_STAGE = (HP3_BM + HP3_BN) * 128, HP3_NST = 3;
+
+__global__ void __launch_bounds__(512, 1) gemm_hp3_kernel(const HpGemmK p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int bid = hp_xcd_remap(blockIdx.x, ntiles);
+  const int m0 = (bid % p.tiles_m) * HP3_BM, n0 = (bid / p.tiles_m) * HP3_BN;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, (int)p.a_bytes, HP_RSRC);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, (int)p.b_bytes, HP_RSRC);
+
+  // LDS-DMA pieces: A rows (8j + wave) * 8 .. + 7 for j = 0..3, B rows (8j + wave) * 8 .. + 7 for j = 0..1
+  unsigned va[4], vb[2];
+  {
+    const int src_slot = (lane & 7) ^ (((lane >> 4) & 3) | ((wave & 1) << 2));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (8 * j + wave) * 8 + (lane >> 3);
+      va[j] = (unsigned)min(m0 + row, p.M - 1) * p.a_pitch + 16u * src_slot;
+      if (j < 2) vb[j] = (unsigned)min(n0 + row, p.N - 1) * p.b_pitch + 16u * src_slot;
+    }
+  }
+  const int kt0 = blockIdx.y * p.kt_per_split;
+  const int nk = min(p.nkt - kt0, p.kt_per_split);
+  auto stage = [&](int buf, int kt) {   // kt >= nk: offsets beyond the planes read zeros (keeps the vmcnt arithmetic uniform)
+    char* base = lds + buf * HP3_STAGE;
+    const int koff = kt < nk ? (kt0 + kt) * 128 : 0x7ff00000;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (8 * j + wave) * 1024), 16, va[j], koff, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + HP3_BM * 128 + (8 * j + wave) * 1024), 16, vb[j], koff, 0, 0);
+  };
+
+  const int frag0 = (lane & 15) * 128 + 16 * ((lane >> 4) ^ ((lane & 15) >> 1));
+  const int a_base = wr * (64 * 128) + frag0;
+  const int b_base = HP3_BM * 128 + wc * (64 * 128) + frag0;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // stage 0 landed (this wave's share); the barrier makes it everyone's
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int nxt2 = cur == 0 ? 2 : cur - 1;          // (cur + 2) % 3: the buffer read during the previous iteration
+    stage(nxt2, kt + 2);
+    const char* sb = lds + cur * HP3_STAGE;
+    f16x8 a[4][2], b[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i][0] = *reinterpret_cast<const f16x8*>(sb + (a_base + i * 2048));
+      a[i][1] = *reinterpret_cast<const f16x8*>(sb + ((a_base ^ 64) + i * 2048));
+      b[i][0] = *reinterpret_cast<const f16x8*>(sb + (b_base + i * 2048));
+      b[i][1] = *reinterpret_cast<const f16x8*>(sb + ((b_base ^ 64) + i * 2048));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], b[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tile kt+1 landed; tile kt+2 stays in flight
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs of the last two iterations
+
+  const int mode = p.splits > 1 ? 0 : ((p.flags & RNNT_GEMM_ACCUM) ? 2 : 1);
+  float* slab = p.splits > 1 ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
+  float bias_v[4], sb4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+    bias_v[j] = (mode != 0 && p.bias && n < p.N) ? p.bias[n] : 0.f;
+    sb4[j] = hp_inv_scale_from_amax(p.b_amax[min(n, p.N - 1)]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + reg;
+      const bool mok = m < p.M;
+      const int mc = mok ? m : 0;
+      const float sa = hp_inv_scale_from_amax(p.a_amax[mc]);
+      float* crow = mode == 0 ? slab + (long)mc * p.N : p.C + (long)(mc / p.c_div) * p.c_so + (long)(mc % p.c_div) * p.c_si;
+      float old[4] = {0.f, 0.f, 0.f, 0.f};
+      if (mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+          if (mok && n < p.N) old[j] = crow[n];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+        if (mok && n < p.N) crow[n] = acc[i][j][reg] * sa * sb4[j] + bias_v[j] + old[j];
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) hp_splitk_reduce_kernel(const HpGemmK p) {
   const long total = (long)p.M * p.N;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -342,7 +465,7 @@ int hp_colmax(const float* x, int64_t rows, int64_t C, int64_t ld, uint32_t* ama
   if (chunks > ceil_div(rows, 64)) chunks = ceil_div(rows, 64);
   if (chunks < 1) chunks = 1;
   const long rpc = ceil_div(rows, chunks);
-  ProfScope prof(RNNT_K_MISC, 4.0 * (double)rows * (double)C, s);
+  ProfScope prof(RNNT_K_HP_SPLIT, 4.0 * (double)rows * (double)C, s);
   hipLaunchKernelGGL(hp_colmax_kernel, dim3((unsigned)ceil_div(C, 256), (unsigned)ceil_div(rows, rpc)), dim3(256), 0, s, x, (long)rows, (int)C,
                      (long)ld, rpc, amax);
   RNNT_CHECK_LAUNCH();
@@ -352,7 +475,7 @@ int hp_colmax(const float* x, int64_t rows, int64_t C, int64_t ld, uint32_t* ama
 int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, void* planes, hipStream_t s) {
   if (rows == 0) return RNNT_OK;
   const long blocks = ceil_div(rows, 4);
-  ProfScope prof(RNNT_K_MISC, 8.0 * (double)rows * (double)K, s);
+  ProfScope prof(RNNT_K_HP_SPLIT, 8.0 * (double)rows * (double)K, s);
   hipLaunchKernelGGL(hp_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, x, (long)rows, (int)K, (long)ld, amax,
                      (char*)planes);
   RNNT_CHECK_LAUNCH();
@@ -362,7 +485,7 @@ int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax
 int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, int64_t shift, const uint32_t* amax, void* planes,
                hipStream_t s) {
   if (R == 0 || K == 0) return RNNT_OK;
-  ProfScope prof(RNNT_K_MISC, 8.0 * (double)R * (double)K, s);
+  ProfScope prof(RNNT_K_HP_SPLIT, 8.0 * (double)R * (double)K, s);
   hipLaunchKernelGGL(hp_split_t_kernel, dim3((unsigned)ceil_div(K, 32), (unsigned)ceil_div(R, 256)), dim3(256), 0, s, x, (int)R, (int)K, (long)ld,
                      (int)Ksrc, (int)shift, amax, (char*)planes);
   RNNT_CHECK_LAUNCH();
@@ -370,7 +493,7 @@ int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, i
 }
 
 size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  const long tiles = ceil_div(M, HP_BM) * ceil_div(N, HP_BN);
+  const long tiles = ceil_div(M, HP_BM) * ceil_div(N, HP_BN);   // the coarser tiling: an upper bound on the splits either kernel takes
   const long nkt = ceil_div(K, HP_BK);
   if (tiles >= 192 || nkt < 64) return 0;
   long want = ceil_div(256, tiles);
@@ -395,7 +518,8 @@ int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t
   k.a_amax = a_amax; k.b_amax = b_amax;
   k.C = C; k.c_div = (int)(c_div > 0x7fffffff ? 0x7fffffff : c_div); k.c_so = c_so; k.c_si = c_si;
   k.bias = bias; k.flags = flags;
-  k.tiles_m = (int)ceil_div(M, HP_BM); k.tiles_n = (int)ceil_div(N, HP_BN);
+  const bool k3 = !getenv("RNNT_GEMM_HP_2STAGE");   // 256x128 tiles / 3-stage LDS ring (default) or 256x256 / 2 stages
+  k.tiles_m = (int)ceil_div(M, HP_BM); k.tiles_n = (int)ceil_div(N, k3 ? HP3_BN : HP_BN);
   const int tiles = k.tiles_m * k.tiles_n;
   int splits = 1;
   if (workspace && tiles < 192 && k.nkt >= 64) {  // too few tiles for 256 CUs and a deep contraction (weight gradients): split K
@@ -410,10 +534,12 @@ int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t
   splits = (int)ceil_div(k.nkt, k.kt_per_split);
   k.splits = splits;
   k.slab = (float*)workspace;
-  RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HP_STAGE));
+  if (k3) RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hp3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HP3_NST * HP3_STAGE));
+  else RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HP_STAGE));
   {
-    ProfScope prof(RNNT_K_GEMM, 2.0 * (double)M * (double)N * (double)K, s);
-    hipLaunchKernelGGL(gemm_hp_kernel, dim3(tiles, splits), dim3(512), 2 * HP_STAGE, s, k);
+    ProfScope prof(RNNT_K_GEMM_HP, 2.0 * (double)M * (double)N * (double)K, s);
+    if (k3) hipLaunchKernelGGL(gemm_hp3_kernel, dim3(tiles, splits), dim3(512), HP3_NST * HP3_STAGE, s, k);
+    else hipLaunchKernelGGL(gemm_hp_kernel, dim3(tiles, splits), dim3(512), 2 * HP_STAGE, s, k);
     RNNT_CHECK_LAUNCH();
     if (splits > 1) {
       const long blocks = ceil_div((long)M * N, 256);

@@ -1384,7 +1384,7 @@ struct LstmWs {
   char* hp_dg;   // bwd: dG (T*B, D*4H)
   char* hp_dgt;  // bwd: dG^T (D*4H, T*B)
   char* hp_yt;   // bwd: time-shifted h^T per direction (D, H, T*B)
-  uint32_t* hp_amax;  // per-row maxima of the operands: [M | N4 | M | N4 | I | I | D*H] words (carve_lstm)
+  uint32_t* hp_amax;  // per-row maxima of the operands: [M | N4 | M | N4 | I | I | D*H | N4] words (carve_lstm)
   size_t total;
 };
 
@@ -1544,7 +1544,7 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
     w.hp_x = w.hp_w = w.hp_dg = w.hp_dgt = w.hp_yt = nullptr;
     w.hp_amax = nullptr;
     if (w.hp) {
-      w.hp_amax = reinterpret_cast<uint32_t*>(take((size_t)(2 * M + 2 * N4 + 2 * I + (int64_t)D * H) * 4));
+      w.hp_amax = reinterpret_cast<uint32_t*>(take((size_t)(2 * M + 3 * N4 + 2 * I + (int64_t)D * H) * 4));
       w.hp_x = take(hp_plane_bytes(M, I) > hp_plane_bytes(I, M) ? hp_plane_bytes(M, I) : hp_plane_bytes(I, M));
       w.hp_w = take(hp_plane_bytes(N4, I) > hp_plane_bytes(I, N4) ? hp_plane_bytes(N4, I) : hp_plane_bytes(I, N4));
       w.hp_dg = take(hp_plane_bytes(M, N4));
@@ -1649,6 +1649,7 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->xcc = w.flags + 16 + w.nflags;
   k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
   k->hw_math = getenv("RNNT_LSTM_EXACT_MATH") ? 0 : 1;
+  k->colmax = k->colmax_h = nullptr;
 }
 
 }  // namespace
@@ -1828,7 +1829,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   auto adopt = [&](const Plan2& q) {
     k.NC = q.NC; k.Hs = q.HS; k.G = q.G; k.Bg = q.Bg; k.Kp = q.Kp;
   };
-  bool fused_db = false;
+  bool fused_db = false, colmax_done = false;
   int db_rows = 0;
   if (make_plan3(d->B, d->H, d->D, cus, true, &p2)) {
     adopt(p2);
@@ -1849,6 +1850,14 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       else LAUNCH_V4_B(N, 2);                                      \
     } while (0)
     if (p2.MB == 4 && nks <= 4 && lstm5_supported(d->T, d->B, d->H, d->D, d->cell)) {  // v5 (lstm5.hip)
+      if (w.hp) {  // the recurrence also leaves the column maxima of dG (the scales of the half-pair dG^T planes): no extra pass
+        const int64_t Mr = (int64_t)T * B, N4r = (int64_t)D * 4 * H;
+        k.colmax = w.hp_amax + Mr + N4r + Mr;
+        k.colmax_h = w.hp_amax + 2 * Mr + 2 * N4r + 2 * I + (int64_t)D * H;
+        RNNT_CHECK_HIP(hipMemsetAsync(k.colmax, 0, (size_t)N4r * 4, s));
+        RNNT_CHECK_HIP(hipMemsetAsync(k.colmax_h, 0, (size_t)N4r * 4, s));
+        colmax_done = true;
+      }
       rc = lstm5_bwd_launch(k, p2, d->cell, s);
     } else if (p2.MB == 5) {  // H = 640: own 80 gate columns (3 k-steps), 48 output blocks over 8 waves
 #define LAUNCH_V45_C(BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<6, BQ_, C, 8, 5, 1>, k, p2, p2.lds_bwd + 8 * 1 * 3 * 3 * 1024, s, "lstm_bwd4", 512)
@@ -1913,7 +1922,8 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   if (w.hp) {  // half-pair planes of dG in both orientations (gemm_hp.hip is NT-only: transposed operands are materialised)
     if (hp_in && bd->dx)
       if ((rc = hp_split(d->gates, M, N4, N4, a_dgr, w.hp_dg, s))) return rc;
-    if ((rc = hp_colmax(d->gates, M, N4, N4, a_dgc, s))) return rc;
+    if (!colmax_done)
+      if ((rc = hp_colmax(d->gates, M, N4, N4, a_dgc, s))) return rc;
     if ((rc = hp_split_t(d->gates, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
   }
   // 2. dX = dG . W_ih'   (needs the permuted weights: rebuild them, the forward copy may have been overwritten)
@@ -1959,7 +1969,8 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   if (w.hp && T > 1) {
     if ((rc = hp_colmax(d->y, M, (int64_t)D * H, (int64_t)D * H, a_y, s))) return rc;
     if (gru) {  // hidden-side gate gradients differ from the input-side ones in the n gate: their own transposed planes
-      if ((rc = hp_colmax(ghid, M, N4, N4, a_dgc, s))) return rc;
+      if (colmax_done) a_dgc = a_y + (int64_t)D * H;   // left there by the v5 recurrence
+      else if ((rc = hp_colmax(ghid, M, N4, N4, a_dgc, s))) return rc;
       if ((rc = hp_split_t(ghid, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
     }
     for (int dir = 0; dir < D; ++dir) {

@@ -401,6 +401,7 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
   const int olen = valid ? p.lens[ob] : 0;
   float dc_carry = 0.f;
   f32x4 db_acc = {0.f, 0.f, 0.f, 0.f}, dbh_acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 cmx = {0.f, 0.f, 0.f, 0.f}, cmxh = {0.f, 0.f, 0.f, 0.f};   // running |dG| maxima of this cell's 4 gate columns
   const int t_first = (d == 0) ? T - 1 : 0;
   const int tdir = (d == 0) ? -1 : 1;
   const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)T * B * D * 4 * H * 4), RSRC_FLAGS);
@@ -511,6 +512,11 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
       }
       db_acc += dg4;
       if constexpr (CELL == 1) dbh_acc += dgh4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cmx[e] = fmaxf(cmx[e], fabsf(dg4[e]));
+        if constexpr (CELL == 1) cmxh[e] = fmaxf(cmxh[e], fabsf(dgh4[e]));
+      }
       *reinterpret_cast<f32x4*>(&dgs[brow * DGS_LD + 4 * (4 * ouq + oi)]) = dgh4;  // own gate column 4*unit + gate
       const float mx = fmaxf(fmaxf(fabsf(dgh4[0]), fabsf(dgh4[1])), fmaxf(fabsf(dgh4[2]), fabsf(dgh4[3])));
       atomicMax(&rowexp[(s & 1) * 16 + brow], __float_as_uint(mx));   // LDS ds_max_u32: the row's maximum over the 64 own columns
@@ -586,6 +592,17 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
     const long row = (long)gid * NBR + brow;
     *reinterpret_cast<f32x4*>(p.dbp + row * 4 * H + 4 * oj) = db_acc;
     if constexpr (CELL == 1) *reinterpret_cast<f32x4*>(p.dbhp + row * 4 * H + 4 * oj) = dbh_acc;
+    if (p.colmax) {   // column maxima of dG for the half-pair planes of the weight-gradient products (max is order-independent)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned a = __float_as_uint(cmx[e]);
+        if (a != 0u) atomicMax(p.colmax + (long)d * 4 * H + 4 * oj + e, a);
+        if constexpr (CELL == 1) {
+          const unsigned b = __float_as_uint(cmxh[e]);
+          if (b != 0u) atomicMax(p.colmax_h + (long)d * 4 * H + 4 * oj + e, b);
+        }
+      }
+    }
   }
   if (p.dbg && tid == 0) {
     for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];

@@ -34,6 +34,8 @@ struct LstmK {
   float* dbp;      // v4 backward: (D*G*NBR, 4H) time sums of the input-side dG per exchange row, or nullptr
   float* dbhp;     // same for the hidden-side dG (GRU)
   int NGL;         // v2+: launch stride of the group index (>= D*G): gid = blockIdx % NGL, blocks with gid >= D*G exit at once
+  unsigned* colmax;    // v5 backward (or nullptr): per gate column (D*4H) running maximum of |dG| over all frames and rows (fp32 bit
+  unsigned* colmax_h;  // patterns, zeroed by the host), input side / hidden side (GRU) — the column scales of the half-pair dG^T planes
   int hw_math;     // v2: v_exp_f32 / v_rcp_f32 cell math (default; measured whole-model loss delta identical to the ocml expf +
                    // IEEE-division form, which RNNT_LSTM_EXACT_MATH=1 selects)
 };
