@@ -518,7 +518,7 @@ int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t
   k.a_amax = a_amax; k.b_amax = b_amax;
   k.C = C; k.c_div = (int)(c_div > 0x7fffffff ? 0x7fffffff : c_div); k.c_so = c_so; k.c_si = c_si;
   k.bias = bias; k.flags = flags;
-  const bool k3 = !getenv("RNNT_GEMM_HP_2STAGE");   // 256x128 tiles / 3-stage LDS ring (default) or 256x256 / 2 stages
+  const bool k3 = getenv("RNNT_GEMM_HP_3STAGE") != nullptr;   // opt-in: 256x128 tiles / 3-stage LDS ring (measured 10-14 % slower than 256x256 / 2 stages)
   k.tiles_m = (int)ceil_div(M, HP_BM); k.tiles_n = (int)ceil_div(N, k3 ? HP3_BN : HP_BN);
   const int tiles = k.tiles_m * k.tiles_n;
   int splits = 1;

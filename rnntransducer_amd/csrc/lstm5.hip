@@ -67,18 +67,21 @@ __device__ __forceinline__ bool poll_tagged(F&& load_and_check, unsigned* status
 }
 
 // ================================================================================================
-// forward.  dynamic LDS: part[2 parities][4 waves][4 blocks][64] f32x4 (32 KB) | wmax[4] | abort
-// NKS: 32-deep k-steps per wave (H = 128 * NKS).  CELL: 0 LSTM, 1 GRU, 2 tanh Elman RNN.
+// forward.  dynamic LDS: part[2 parities][NWV waves][MB blocks][64] f32x4 | wmax[8] | abort | pubs[16][HS]
+// NKS: 32-deep k-steps per wave (Kp = NWV * 32 * NKS >= H, zero padded).  CELL: 0 LSTM, 1 GRU, 2 tanh Elman RNN.
+// NWV x MB: 4 x 4 (H = 128..512: 16 units per workgroup) or 8 x 5 (H = 640: 20 units per workgroup so that a sync group has 32
+// members and fits one XCD; K padded to 768).  Wave w < MB owns gate-column block w (one cell per lane).
 // ================================================================================================
-template <int NKS, int CELL>
-__global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
+template <int NKS, int CELL, int NWV = 4, int MB = 4>
+__global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
-  constexpr int MB = 4, HS = 16, Kw = 32 * NKS;
+  constexpr int HS = 4 * MB, Kw = 32 * NKS;
+  static_assert(MB <= NWV, "one owner wave per gate-column block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* part = reinterpret_cast<f32x4*>(smem);
-  float* wmax = reinterpret_cast<float*>(part + 2 * 4 * MB * 64);
-  int* abort_lds = reinterpret_cast<int*>(wmax + 4);
-  unsigned* pubs = reinterpret_cast<unsigned*>(abort_lds + 4);   // [16 rows][16 units] packed dwords (write-through path only)
+  float* wmax = reinterpret_cast<float*>(part + 2 * NWV * MB * 64);
+  int* abort_lds = reinterpret_cast<int*>(wmax + 8);
+  unsigned* pubs = reinterpret_cast<unsigned*>(abort_lds + 4);   // [16 rows][HS units] packed dwords (write-through path only)
 
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
       for (int ks = 0; ks < NKS; ++ks) {
         const int k = wave * Kw + 32 * ks + 8 * lq;
         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-        if (gate < NGATE) {
+        if (gate < NGATE && k < H) {   // H is a multiple of 8: an 8-chunk is inside or outside as a whole
           lo = *reinterpret_cast<const f32x4*>(row + k);
           hi = *reinterpret_cast<const f32x4*>(row + k + 4);
         }
@@ -120,7 +123,9 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
     if (lane == 0) wmax[wave] = m;
     if (tid == 0) *abort_lds = 0;
     __syncthreads();
-    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    m = wmax[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) m = fmaxf(m, wmax[w]);
     // power-of-two scale bringing the slice maximum into [2^14, 2^15)
     int eb = (int)((__float_as_uint(m) >> 23) & 255u);
     eb = eb < 15 ? 15 : eb;
@@ -140,14 +145,16 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
     hx_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.hx) + ((long)par * NG + gid) * hx_bytes, 0, (int)hx_bytes,
                                                      RSRC_FLAGS);
 
-  // one cell per lane: unit 4*wave + lq of this workgroup, batch row lrow of this group
+  // one cell per lane of waves 0..MB-1: unit 4*wave + lq of this workgroup, batch row lrow of this group (further waves only
+  // contribute their K-slice of the product)
+  const bool ownw = wave < MB;
   const int brow = lrow;
-  const int ob = b0 + brow, oj = j0 + 4 * wave + lq;
-  const bool inrow = brow < NBR;
-  const bool valid = brow < p.Bg && ob < B;
+  const int ob = b0 + brow, oj = j0 + 4 * (ownw ? wave : 0) + lq;
+  const bool inrow = brow < NBR;                       // exchange row of the group (gather side: every wave)
+  const bool valid = ownw && brow < p.Bg && ob < B;
   const int olen = valid ? p.lens[ob] : 0;
   float c_state = 0.f;
-  const float bhn = CELL == 1 ? p.b_hh[d][2 * H + oj] : 0.f;
+  const float bhn = (CELL == 1 && ownw) ? p.b_hh[d][2 * H + oj] : 0.f;
   // stash / prefetch through buffer resources with per-lane byte offsets: inactive lanes carry an out-of-range offset (loads
   // return 0, stores are dropped), so the loop body has NO divergent branch around a memory operation and hipcc can count
   // exactly how many younger operations may stay in flight when it waits for the gathered operands (a vmcnt(0) there would also
@@ -163,7 +170,7 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
   int c_off = valid ? (int)((((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
   int y_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * H + oj) * 4) : OOB;
   const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
-  const int hx_off = inrow ? (brow * Kp + oj) * 4 : OOB;
+  const int hx_off = (ownw && inrow) ? (brow * Kp + oj) * 4 : OOB;
   const int gat_off = inrow ? (brow * Kp + wave * Kw + 8 * lq) * 4 : 0x7ffffff0;  // rows beyond the group read 0 and are not checked
   unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
   const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
@@ -171,20 +178,24 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
   auto run = [&](auto local_tag) -> bool {
   constexpr bool LOCAL = decltype(local_tag)::value;
   u32x4 raw[NKS][2];   // the next step's operand dwords: loads are issued right behind this step's publication
+  // k-steps beyond H (zero padding of K, H = 640 form) have no producer: not loaded (zeros), not checked
   auto issue_gather = [&](int s_next) {
     const __amdgpu_buffer_rsrc_t src = hx_rsrc[(s_next - 1) & 1];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      raw[ks][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, gat_off + 128 * ks, 0, AUX_SC1));
-      raw[ks][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, gat_off + 128 * ks + 16, 0, AUX_SC1));
+      const int off = (wave * Kw + 32 * ks < H) ? gat_off + 128 * ks : OOB;
+      raw[ks][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, off, 0, AUX_SC1));
+      raw[ks][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, off + 16, 0, AUX_SC1));
     }
   };
   auto tags_ok = [&](unsigned want) -> bool {
     unsigned bad = 0;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
+      if (wave * Kw + 32 * ks < H) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bad |= (raw[ks][0][e] ^ want) | (raw[ks][1][e] ^ want);
+        for (int e = 0; e < 4; ++e) bad |= (raw[ks][0][e] ^ want) | (raw[ks][1][e] ^ want);
+      }
     return !inrow || (bad & TAG_MASK) == 0u;
   };
   f32x4 xp = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_off, 0, 0));
@@ -222,13 +233,16 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
       DBG_STAMP(2);
     }
     if (!ok) *abort_lds = 1;   // benign race: any wave that gave up makes the whole workgroup leave after the barrier
-    f32x4* pp = part + (s & 1) * (4 * MB * 64);
+    f32x4* pp = part + (s & 1) * (NWV * MB * 64);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) pp[(wave * MB + mb) * 64 + lane] = acc[mb];
     __syncthreads();
     DBG_STAMP(3);   // partial write + barrier (includes the skew between this workgroup's waves)
     if (*abort_lds != 0) return false;
-    f32x4 rec = (pp[(0 * MB + wave) * 64 + lane] + pp[(1 * MB + wave) * 64 + lane]) + (pp[(2 * MB + wave) * 64 + lane] + pp[(3 * MB + wave) * 64 + lane]);
+    const int ownb = ownw ? wave : 0;
+    f32x4 rec = pp[ownb * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) rec += pp[(w * MB + ownb) * 64 + lane];
     rec *= out_scale;
     const bool active = valid && t < olen;
     float hval = 0.f;
@@ -262,12 +276,16 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
         __builtin_amdgcn_raw_buffer_store_b32(v, hx_rsrc[s & 1], hx_off, 0, 0);   // stays in the group's L2
       } else {
         // group spans XCDs: write-through stores, and a 4-byte sc1 store is one fabric write each (12x the time per byte of a
-        // 16-byte one): gather the workgroup's 16 rows x 16 units in LDS and let wave 0 store 64 granules of 16 bytes
-        pubs[brow * 16 + 4 * wave + lq] = (unsigned)v;
+        // 16-byte one): gather the workgroup's 16 rows x HS units in LDS and let wave 0 store them as granules of 16 bytes
+        if (ownw) pubs[brow * HS + 4 * wave + lq] = (unsigned)v;
         __syncthreads();
         if (wave == 0) {
-          const i32x4 gran = *reinterpret_cast<const i32x4*>(pubs + lrow * 16 + 4 * lq);
-          __builtin_amdgcn_raw_buffer_store_b128(gran, hx_rsrc[s & 1], lrow < NBR ? (lrow * Kp + j0 + 4 * lq) * 4 : OOB, 0, AUX_SC1);
+#pragma unroll
+          for (int gi = lane; gi < 16 * MB; gi += 64) {
+            const int r = gi / MB, q = gi % MB;
+            const i32x4 gran = *reinterpret_cast<const i32x4*>(pubs + r * HS + 4 * q);
+            __builtin_amdgcn_raw_buffer_store_b128(gran, hx_rsrc[s & 1], r < NBR ? (r * Kp + j0 + 4 * q) * 4 : OOB, 0, AUX_SC1);
+          }
         }
       }
     }
@@ -313,14 +331,14 @@ __global__ void __launch_bounds__(256) lstm_fwd5_kernel(const LstmK p) {
 //   a granule until both halves carry the wanted generation.  No flag, no drain, no publication barrier.
 //   Arithmetic: dG rows scaled per (row, workgroup) by a power of two from the row's maximum over the 64 own columns (LDS
 //   ds_max), W_hh by the slice maximum; 3 f16 products; the product is descaled before it is published.
-// dynamic LDS: red[256] f32x4 | dgs[16][DGS_LD] float | rowexp[2][16] | wmax[4] | abort
+// dynamic LDS: red[NT] f32x4 | dgs[16][DGS_LD] float | rowexp[2][16] | wmax[8] | abort
+// NMB: 16-unit output blocks per wave (Kp / 16 / NWV).  NWV x MB: 4 x 4 (H = 128..512) or 8 x 5 (H = 640, K padded to 768).
 // ================================================================================================
-template <int NKS, int BQ, int CELL>
-__global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
+template <int NMB, int BQ, int CELL, int NWV = 4, int MB = 4>
+__global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
-  constexpr int HS = 16, UQ = 4, NT = 256;
-  constexpr int NMB = 2 * NKS;          // 16-unit output blocks per wave (H / 16 / 4)
-  constexpr int KSB = 2;                // 32-deep k-steps over the 64 own gate columns
+  constexpr int HS = 4 * MB, UQ = MB, NT = 64 * NWV;
+  constexpr int KSB = (16 * MB + 31) / 32;   // 32-deep k-steps over the own gate columns (zero padded)
   constexpr int NBR = 4 * BQ;           // exchange rows of the group
   constexpr int DGS_LD = 32 * KSB + 4;
   constexpr int OOB = 0x7ffffff0;
@@ -329,7 +347,7 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
   float* dgs = reinterpret_cast<float*>(red + NT);
   unsigned* rowexp = reinterpret_cast<unsigned*>(dgs + 16 * DGS_LD);
   float* wmax = reinterpret_cast<float*>(rowexp + 32);
-  int* abort_lds = reinterpret_cast<int*>(wmax + 4);
+  int* abort_lds = reinterpret_cast<int*>(wmax + 8);
 
   const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -356,11 +374,13 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
       for (int ks = 0; ks < KSB; ++ks) {
         const int c = 32 * ks + 8 * lq;   // own gate column, a multiple of 8: units c>>2 and (c>>2)+1, gates 0..3 each
         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (u < H) {   // output units beyond H: zero padding of K (H = 640 form)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (e < NGATE) {
-            lo[e] = W[(long)(e * H + j0 + (c >> 2)) * H + u];
-            hi[e] = W[(long)(e * H + j0 + (c >> 2) + 1) * H + u];
+          for (int e = 0; e < 4; ++e) {
+            if (e < NGATE) {
+              if ((c >> 2) < HS) lo[e] = W[(long)(e * H + j0 + (c >> 2)) * H + u];
+              if ((c >> 2) + 1 < HS) hi[e] = W[(long)(e * H + j0 + (c >> 2) + 1) * H + u];
+            }
           }
         }
         raw[mb][ks][0] = lo;
@@ -376,7 +396,9 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
     if (tid < 32) rowexp[tid] = 0u;
     for (int i = tid; i < 16 * DGS_LD; i += NT) dgs[i] = 0.f;
     __syncthreads();
-    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    m = wmax[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) m = fmaxf(m, wmax[w]);
     int eb = (int)((__float_as_uint(m) >> 23) & 255u);
     eb = eb < 15 ? 15 : eb;
     const float wscale = m > 0.f ? __uint_as_float((unsigned)(268 - eb) << 23) : 1.f;
@@ -415,8 +437,9 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
   const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
 
   // gather: thread -> (row, unit quad) pair gpr and producer class gq; it sums the partial slices of producers gq, gq + NQ, ...
-  constexpr int NPAIR = NBR * UQ, NQ = NT / NPAIR, NLD = (32 + NQ - 1) / NQ;   // NC <= 32
+  constexpr int NPAIR = NBR * UQ, NQ = NT / NPAIR, NLD = (32 + NQ - 1) / NQ;   // NC <= 32; threads beyond NQ * NPAIR only help elsewhere
   const int gq = tid / NPAIR, gpr = tid % NPAIR;
+  const bool gact = gq < NQ;
   const int grow = gpr / UQ, guq = gpr % UQ;
   const int gat_base = ((gq * NBR + grow) * Kp + j0 + 4 * guq) * 4;   // bytes; + NQ producers per visit
   const int gat_step = NQ * NBR * Kp * 4;
@@ -432,7 +455,7 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
     const __amdgpu_buffer_rsrc_t src = px_rsrc[(s_next - 1) & 1];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const bool okp = gq + NQ * i < p.NC;
+      const bool okp = gact && gq + NQ * i < p.NC;
       gr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, okp ? gat_base + i * gat_step : OOB, 0, AUX_SC1));
     }
   };
@@ -440,7 +463,7 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
     unsigned bad = 0;
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
-      if (gq + NQ * i < p.NC) bad |= (gr[i][0] ^ want) | (gr[i][2] ^ want);
+      if (gact && gq + NQ * i < p.NC) bad |= (gr[i][0] ^ want) | (gr[i][2] ^ want);
     return (bad & 1u) == 0u;
   };
   // prefetch of step 0
@@ -481,7 +504,7 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
     if (owner) {
       float dh = active ? dyv : 0.f;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) dh += red[q * NPAIR + brow * UQ + ouq][oi];
+      for (int q = 0; q < NQ; ++q) dh += red[q * NPAIR + brow * UQ + ouq][oi];   // (threads with gq >= NQ wrote zeros: never read)
       if (active) {
         if constexpr (CELL == 0) {
           const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
@@ -616,19 +639,26 @@ __global__ void __launch_bounds__(256) lstm_bwd5_kernel(const LstmK p) {
 }  // namespace
 
 // host side ----------------------------------------------------------------------------------------------------
-// v5 takes H in {128, 256, 384, 512} (4 waves, one k-quarter each), cells LSTM / GRU / tanh RNN; everything else stays on v3 / v4
+// v5 takes H in {128, 256, 384, 512} (4 waves x 16 units) and H = 640 (8 waves x 20 units, K padded to 768), cells LSTM / GRU /
+// tanh RNN; everything else stays on v3 / v4
 bool lstm5_supported(int T, int B, int H, int D, int cell) {
   if (getenv("RNNT_LSTM_NO_V5") || getenv("RNNT_LSTM_V1") || getenv("RNNT_LSTM_V2") || getenv("RNNT_LSTM_EXACT_MATH")) return false;
   if ((long)T * B * D * 4 * H * 4 >= (1l << 31)) return false;   // the stash is addressed with 32-bit buffer offsets
-  return H % 128 == 0 && H >= 128 && H <= 512 && cell != RNNT_CELL_RNN_RELU;
+  const bool h640 = H == 640 && !getenv("RNNT_LSTM_NO_H640_FORM") && !getenv("RNNT_LSTM_NO_8WAVE");
+  return ((H % 128 == 0 && H >= 128 && H <= 512) || h640) && cell != RNNT_CELL_RNN_RELU;
 }
 
-size_t lstm5_fwd_lds() { return (size_t)2 * 4 * 4 * 64 * 16 + 16 + 16 + 1024; }
-
 int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
-  const size_t lds = lstm5_fwd_lds();
   const int nks = k.Kp / 128;
   int rc = RNNT_ERR_UNSUPPORTED;
+  if (pl.MB == 5) {   // H = 640
+    const size_t lds = (size_t)2 * 8 * 5 * 64 * 16 + 32 + 16 + 16 * 20 * 4;
+    if (cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd5_kernel<3, 0, 8, 5>, k, pl, lds, s, "lstm_fwd5", 512);
+    else if (cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd5_kernel<3, 1, 8, 5>, k, pl, lds, s, "lstm_fwd5", 512);
+    else rc = launch_persistent2(lstm_fwd5_kernel<3, 2, 8, 5>, k, pl, lds, s, "lstm_fwd5", 512);
+    return rc;
+  }
+  const size_t lds = (size_t)2 * 4 * 4 * 64 * 16 + 32 + 16 + 16 * 16 * 4;
 #define L5(N)                                                                                              \
   do {                                                                                                     \
     if (cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd5_kernel<N, 0>, k, pl, lds, s, "lstm_fwd5");      \
@@ -644,33 +674,38 @@ int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
   return rc;
 }
 
-size_t lstm5_bwd_lds() { return (size_t)256 * 16 + 16 * (32 * 2 + 4) * 4 + 32 * 4 + 16 + 16; }
-
 int lstm5_bwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
-  const size_t lds = lstm5_bwd_lds();
   const int nks = k.Kp / 128;
   int rc = RNNT_ERR_UNSUPPORTED;
-#define B5C(N, Q, C) rc = launch_persistent2(lstm_bwd5_kernel<N, Q, C>, k, pl, lds, s, "lstm_bwd5")
-#define B5Q(N, C)                       \
-  do {                                  \
-    if (pl.BQ == 1) B5C(N, 1, C);       \
-    else if (pl.BQ == 2) B5C(N, 2, C);  \
-    else B5C(N, 4, C);                  \
+#define B5Q(NM, C, ...)                                                                               \
+  do {                                                                                                \
+    if (pl.BQ == 1) rc = launch_persistent2(lstm_bwd5_kernel<NM, 1, C, ##__VA_ARGS__>, k, pl, lds, s, "lstm_bwd5", threads);       \
+    else if (pl.BQ == 2) rc = launch_persistent2(lstm_bwd5_kernel<NM, 2, C, ##__VA_ARGS__>, k, pl, lds, s, "lstm_bwd5", threads);  \
+    else rc = launch_persistent2(lstm_bwd5_kernel<NM, 4, C, ##__VA_ARGS__>, k, pl, lds, s, "lstm_bwd5", threads);                  \
   } while (0)
-#define B5(N)                                        \
+  if (pl.MB == 5) {   // H = 640: 80 own gate columns (3 k-steps), 48 output blocks over 8 waves
+    const int threads = 512;
+    const size_t lds = (size_t)512 * 16 + 16 * (32 * 3 + 4) * 4 + 32 * 4 + 32 + 16;
+    if (cell == RNNT_CELL_LSTM) B5Q(6, 0, 8, 5);
+    else if (cell == RNNT_CELL_GRU) B5Q(6, 1, 8, 5);
+    else B5Q(6, 2, 8, 5);
+    return rc;
+  }
+  const int threads = 256;
+  const size_t lds = (size_t)256 * 16 + 16 * (32 * 2 + 4) * 4 + 32 * 4 + 32 + 16;
+#define B5(NM)                                       \
   do {                                               \
-    if (cell == RNNT_CELL_LSTM) B5Q(N, 0);           \
-    else if (cell == RNNT_CELL_GRU) B5Q(N, 1);       \
-    else B5Q(N, 2);                                  \
+    if (cell == RNNT_CELL_LSTM) B5Q(NM, 0);          \
+    else if (cell == RNNT_CELL_GRU) B5Q(NM, 1);      \
+    else B5Q(NM, 2);                                 \
   } while (0)
-  if (nks == 1) B5(1);
-  else if (nks == 2) B5(2);
-  else if (nks == 3) B5(3);
-  else if (nks == 4) B5(4);
+  if (nks == 1) B5(2);
+  else if (nks == 2) B5(4);
+  else if (nks == 3) B5(6);
+  else if (nks == 4) B5(8);
   else set_error("lstm_bwd5: H = %d not supported", k.H);
 #undef B5
 #undef B5Q
-#undef B5C
   return rc;
 }
 

@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle shares of one step of the v2 LSTM recurrences at BASELINE config 2 layer shapes.
+"""Diagnostic: per-phase cycle shares of one step of the persistent LSTM recurrences (v5 by default; RNNT_LSTM_NO_V5=1: v3/v4) at BASELINE config 2 layer shapes.
    RNNT_LSTM_DBG=1 python tools/lstm_phase_probe.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,6 +15,8 @@ lstm = HipLSTM(I, H, 1, bidirectional=True).cuda()
 x = torch.randn(T, B, I, device="cuda", requires_grad=True)
 lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
 names = ["prefetch issue", "flag wait", "gather+MFMA", "reduce+cell math", "drain+barrier+flag", "stash stores"]
+names5b = ["loop top (dropout mask)", "tagged poll (wait for partial dh)", "partial sums + barrier", "cell math + dG image + barrier",
+           "scale + MFMA + publication", "gather issue + prefetch + stash"]
 names5 = ["loop top", "tagged poll (wait for operands)", "de-interleave + MFMA", "partial write + barrier", "reduce + cell math + publish",
           "gather issue + stash + prefetch"]
 
@@ -27,8 +29,8 @@ def read(ws, tag):
     tot = out[:, :6].sum(1).astype(np.float64)
     print(f"--- {tag}: cycles/step per phase (median over 256 workgroups; min..max), total {np.median(tot) / T:.0f} cyc/step")
     print(f"   xcd-local groups: {int(out[:, 6].sum())}/256 workgroups; XCC ids of blocks 0..15: {out[:16, 7].astype(int).tolist()}")
-    v5 = tag == "forward" and not os.environ.get("RNNT_LSTM_NO_V5")
-    for i, n in enumerate(names5 if v5 else names):
+    v5 = not os.environ.get("RNNT_LSTM_NO_V5")
+    for i, n in enumerate((names5 if tag == "forward" else names5b) if v5 else names):
         v = out[:, i].astype(np.float64) / T
         print(f"   {n:22s} {np.median(v):8.0f}   ({v.min():.0f} .. {v.max():.0f})")
 
