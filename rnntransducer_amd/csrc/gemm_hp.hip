@@ -244,6 +244,8 @@ __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+    // (measured in one process, tools/gemm_hp_ab.py: issuing the LDS-DMA of waves 4-7 half a tile later than that of their SIMD
+    // partners 0-3 is 5 % SLOWER, s_setprio around the MFMA clusters 1 % slower, 256 x 128 tiles with a 3-stage ring 13 % slower)
     if (kt + 1 < nk) stage(cur ^ 1, kt0 + kt + 1);   // lands under this tile's 96 MFMAs
     const char* sb = lds + cur * HP_STAGE;
     f16x8 a[4][2], b[2][2];
