@@ -225,12 +225,15 @@ int rnnt_hip_joint_loss_fwd_bwd(const float* A, int64_t a_sb, int64_t a_st, cons
 
 /* The same in two calls, for autograd: the forward is rnnt_hip_joint_loss_fwd_bwd with dA = dC = NULL (it leaves
  * log-softmax terms, alpha, beta and log Z in `workspace`); this runs the gradient kernels from that workspace on the SAME
- * A / C / bias / labels / lengths, with the upstream gradient per utterance: d(sum_b gscale * gvec[b] * nll_b)/dA,dC
- * (gvec (B) device, or NULL = ones).  reduction="mean" of model.py:39 arrives here as gvec[b] = 1/B. */
+ * A / C / bias / labels / lengths, with the upstream gradient per utterance: d(sum_b gscale * gvec[b * gvec_stride] * nll_b)/dA,dC
+ * (gvec device, gvec_stride 1 = one value per utterance, 0 = ONE scalar for all; NULL = ones).  reduction="mean" of model.py:39
+ * arrives here as gscale = 1/B with gvec = the 0-d gradient of the mean (stride 0). */
 int rnnt_hip_joint_loss_bwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,
                             const float* bias, const int32_t* labels, const int32_t* t_lens, const int32_t* u_lens,
                             int32_t B, int32_t T, int32_t U1, int32_t V, int32_t blank, float gscale, const float* gvec,
-                            float* dA, float* dC, void* workspace, size_t workspace_bytes, void* stream);
+                            int32_t gvec_stride, float* dA, float* dC, void* workspace, size_t workspace_bytes, void* stream);
+/* out[0] = scale * sum_i x[i] in a fixed order (reduction="mean" / "sum" of the per-utterance losses, model.py:39). */
+int rnnt_hip_scaled_sum_f32(const float* x, int32_t n, float scale, float* out, void* stream);
 
 /* Materialising joint for RNNTransducer.forward() (model.py:47-50): logits (B,T,U1,V) = A + C + bias. */
 int rnnt_hip_joint_logits_fwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,

@@ -85,8 +85,9 @@ SYMBOLS = {
                                                C.c_void_p, C.c_void_p, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_float,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_joint_loss_bwd": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p,
-                                           C.c_void_p, C.c_void_p, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_float, C.c_void_p, c_i32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnnt_hip_scaled_sum_f32": (C.c_int, [C.c_void_p, c_i32, C.c_float, C.c_void_p, C.c_void_p]),
     "rnnt_hip_joint_logits_fwd": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, c_i64, C.c_void_p, c_i32, c_i32,
                                              c_i32, c_i32, C.c_void_p, C.c_void_p]),
     "rnnt_hip_loss_from_logits_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i32, c_i32, c_i32,

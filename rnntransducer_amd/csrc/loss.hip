@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
                                                        const double* __restrict__ alpha, const double* __restrict__ beta,
                                                        const double* __restrict__ ll, int T, int U1, int V, int blank,
                                                        long a_sb, long a_st, long c_sb, long c_su, float gscale_in,
-                                                       const float* __restrict__ gvec,
+                                                       const float* __restrict__ gvec, int gvec_stride,
                                                        float* __restrict__ dA, float* __restrict__ dCp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CellS* cells = reinterpret_cast<CellS*>(smem);
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
   const int Tb = t_lens[b], Ub = u_lens[b];
   const long rowbase = (long)b * U1 * T;
   const double logZ = ll[b];
-  const float gscale = gvec ? gscale_in * gvec[b] : gscale_in;  // per-utterance upstream gradient (1/B under reduction="mean")
+  const float gscale = gvec ? gscale_in * gvec[(long)b * gvec_stride] : gscale_in;  // upstream gradient per utterance (stride 0: one scalar)
   const float* Ab = A + (long)b * a_sb;
   const float* Cb = C + (long)b * c_sb;
   float* dCtile = dCp + ((long)b * ntiles + tile) * U1 * V;
@@ -418,9 +418,9 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
 
 __global__ void __launch_bounds__(256) reduce_dc_kernel(const float* __restrict__ dCp, int ntiles, long per_b, int V,
                                                         long c_sb, long c_su, float gscale_in, const float* __restrict__ gvec,
-                                                        float* __restrict__ dC) {
+                                                        int gvec_stride, float* __restrict__ dC) {
   const int b = blockIdx.y;
-  const float gscale = gvec ? gscale_in * gvec[b] : gscale_in;
+  const float gscale = gvec ? gscale_in * gvec[(long)b * gvec_stride] : gscale_in;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= per_b) return;
   const float* src = dCp + (long)b * ntiles * per_b + i;
@@ -481,6 +481,14 @@ __global__ void nll_kernel(const double* __restrict__ ll, int B, float* __restri
   if (b < B) nll[b] = (float)(-ll[b]);
 }
 
+// out[0] = scale * sum_i x[i]: one wavefront, fixed order (lane partial sums over i = lane, lane + 64, ... then a butterfly)
+__global__ void __launch_bounds__(64) scaled_sum_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += x[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
 struct LossWs {
   float *blk, *emit;
   double *alpha, *beta, *ll;
@@ -539,8 +547,8 @@ using namespace rnnt;
 
 static int launch_grad_sep(const LossWs& w, const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,
                            const float* bias, const int32_t* labels, const int32_t* t_lens, const int32_t* u_lens, int32_t B,
-                           int32_t T, int32_t U1, int32_t V, int32_t blank, float gscale, const float* gvec, float* dA, float* dC,
-                           hipStream_t s) {
+                           int32_t T, int32_t U1, int32_t V, int32_t blank, float gscale, const float* gvec, int gvec_stride, float* dA,
+                           float* dC, hipStream_t s) {
   const int ntiles = (int)ceil_div(T, TT);
   const double cells = (double)B * T * U1;
   const size_t lds = (size_t)TT * U1 * sizeof(CellS) + (size_t)U1 * 64 * 4 * 2 + (size_t)U1 * 4;
@@ -549,11 +557,11 @@ static int launch_grad_sep(const LossWs& w, const float* A, int64_t a_sb, int64_
     RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)grad_sep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope prof(RNNT_K_LATGRAD, 4.0 * 2.0 * ((double)B * T * V + (double)B * U1 * V) + 24.0 * cells, s);
   hipLaunchKernelGGL(grad_sep_kernel, dim3(ntiles, B), dim3(256), lds, s, A, C, bias, labels, t_lens, u_lens, w.blk,
-                     w.emit, w.alpha, w.beta, w.ll, T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, gscale, gvec, dA, w.dCp);
+                     w.emit, w.alpha, w.beta, w.ll, T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, gscale, gvec, gvec_stride, dA, w.dCp);
   RNNT_CHECK_LAUNCH();
   const long per_b = (long)U1 * V;
   hipLaunchKernelGGL(reduce_dc_kernel, dim3((unsigned)ceil_div(per_b, 256), B), dim3(256), 0, s, w.dCp, ntiles, per_b,
-                     V, (long)c_sb, (long)c_su, gscale, gvec, dC);
+                     V, (long)c_sb, (long)c_su, gscale, gvec, gvec_stride, dC);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }
@@ -586,24 +594,32 @@ extern "C" int rnnt_hip_joint_loss_fwd_bwd(const float* A, int64_t a_sb, int64_t
   if (int rc = launch_alphabeta(w, t_lens, u_lens, B, T, U1, s)) return rc;
   hipLaunchKernelGGL(nll_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, w.ll, B, nll);
   RNNT_CHECK_LAUNCH();
-  if (dA) return launch_grad_sep(w, A, a_sb, a_st, C, c_sb, c_su, bias, labels, t_lens, u_lens, B, T, U1, V, blank, gscale, nullptr, dA, dC, s);
+  if (dA) return launch_grad_sep(w, A, a_sb, a_st, C, c_sb, c_su, bias, labels, t_lens, u_lens, B, T, U1, V, blank, gscale, nullptr, 0, dA, dC, s);
   return RNNT_OK;
 }
 
 extern "C" int rnnt_hip_joint_loss_bwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,
                                        const float* bias, const int32_t* labels, const int32_t* t_lens, const int32_t* u_lens,
                                        int32_t B, int32_t T, int32_t U1, int32_t V, int32_t blank, float gscale,
-                                       const float* gvec, float* dA, float* dC, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+                                       const float* gvec, int32_t gvec_stride, float* dA, float* dC, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   // second half of rnnt_hip_joint_loss_fwd_bwd: the workspace still holds blk / emit / alpha / beta / logZ of a forward call
   // (dA = dC = NULL) on the SAME A, C, bias, labels, lengths
   RNNT_CHECK_ARG(labels && t_lens && u_lens && B >= 1 && T >= 1 && U1 >= 1 && V >= 2 && blank >= 0 && blank < V,
                  "joint_loss_bwd: bad dims / null pointer");
   RNNT_CHECK_ARG(A && C && bias && dA && dC, "joint_loss_bwd: null A/C/bias/dA/dC");
+  RNNT_CHECK_ARG(gvec_stride == 0 || gvec_stride == 1, "joint_loss_bwd: gvec_stride must be 0 (one scalar) or 1 (per utterance)");
   const LossWs w = carve(workspace, B, T, U1, V, true);
   RNNT_CHECK_ARG(workspace && workspace_bytes >= w.total, "joint_loss_bwd: workspace too small (%zu < %zu)", workspace_bytes, w.total);
-  return launch_grad_sep(w, A, a_sb, a_st, C, c_sb, c_su, bias, labels, t_lens, u_lens, B, T, U1, V, blank, gscale, gvec, dA, dC,
-                         (hipStream_t)stream);
+  return launch_grad_sep(w, A, a_sb, a_st, C, c_sb, c_su, bias, labels, t_lens, u_lens, B, T, U1, V, blank, gscale, gvec, gvec_stride, dA,
+                         dC, (hipStream_t)stream);
+}
+
+extern "C" int rnnt_hip_scaled_sum_f32(const float* x, int32_t n, float scale, float* out, void* stream) {
+  RNNT_CHECK_ARG(x && out && n >= 0, "scaled_sum: bad arguments");
+  hipLaunchKernelGGL(scaled_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x, n, scale, out);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
 }
 
 extern "C" int rnnt_hip_joint_logits_fwd(const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb,

@@ -1351,16 +1351,50 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ W, const long* __
   }
 }
 
-__global__ void embedding_bwd_kernel(const float* __restrict__ dE, const long* __restrict__ idx, long M, int H, int V,
-                                     long pad, float* __restrict__ dW, int accumulate) {
-  // one workgroup per vocabulary row: fixed-order sum over the tokens that hit it (deterministic, no atomics)
-  const int v = blockIdx.x;
+__global__ void __launch_bounds__(256) embedding_bwd_kernel(const float* __restrict__ dE, const long* __restrict__ idx, long M, int H, int V,
+                                                            long pad, float* __restrict__ dW, int accumulate) {
+  // one workgroup per vocabulary row: the tokens that hit it are compacted IN ORDER (ballot prefix) into LDS, then summed in that
+  // fixed order (deterministic, no atomics) — the scan over all M tokens is done once per row, not once per feature
+  constexpr int CAP = 2048;
+  __shared__ int list[CAP];
+  __shared__ int wcnt[4], nlist;
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (v == pad) return;
-  for (int h = threadIdx.x; h < H; h += blockDim.x) {
-    float s = 0.f;
-    for (long m = 0; m < M; ++m)
-      if (idx[m] == v) s += dE[m * H + h];
-    dW[(long)v * H + h] = accumulate ? dW[(long)v * H + h] + s : s;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // features tid, tid + 256, ... (H <= 1024 keeps everything in registers; more: extra passes)
+  for (int h0 = 0; h0 < H; h0 += 1024) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = 0.f;
+    for (long mb = 0; mb < M; mb += CAP) {   // batches of CAP tokens
+      if (tid == 0) nlist = 0;
+      __syncthreads();
+      const long mend = min(M, mb + CAP);
+      for (long m0 = mb; m0 < mend; m0 += 256) {
+        const long m = m0 + tid;
+        const bool hit = m < mend && idx[m] == v;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int base = nlist;
+        for (int w = 0; w < wave; ++w) base += wcnt[w];
+        if (hit) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)(m - mb);
+        __syncthreads();
+        if (tid == 0) nlist += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+      }
+      const int n = nlist;
+      for (int i = 0; i < n; ++i) {
+        const float* row = dE + (mb + list[i]) * H + h0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (h0 + tid + 256 * q < H) acc[q] += row[tid + 256 * q];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int h = h0 + tid + 256 * q;
+      if (h < H) dW[(long)v * H + h] = accumulate ? dW[(long)v * H + h] + acc[q] : acc[q];
+    }
   }
 }
 

@@ -107,9 +107,8 @@ class RNNTransducer(_Base):
     def training_step(self, batch, batch_idx):
         assert not getattr(self.args, "move_metrics_to_cpu", False), "DDP only (model.py:53)"
         input_audios, audio_lengths, tensor_audio_lengths, input_texts, text_lengths, targets, target_lengths = batch
-        nll = self.jointnet.loss(input_audios, tensor_audio_lengths, input_texts, targets, target_lengths,
-                                 self.blank_token_id)
-        loss = nll.mean()  # reduction="mean" (model.py:39)
+        loss = self.jointnet.loss(input_audios, tensor_audio_lengths, input_texts, targets, target_lengths,
+                                  self.blank_token_id, reduction="mean")  # reduction="mean" (model.py:39), inside the library
         if pl is not None and getattr(self, "_trainer", None) is not None:
             self.log("train_loss", loss, sync_dist=True)
         return {"loss": loss}

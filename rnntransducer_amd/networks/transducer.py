@@ -47,14 +47,16 @@ class JointNet(nn.Module):
         dec = self.decoder.forward_time_major(input_texts, lengths_to_device(text_lengths, dev))
         return JointLogitsFn.apply(enc, dec, self.fc.weight, self.fc.bias)
 
-    def loss(self, input_audios, tensor_audio_lengths, input_texts, targets, target_lengths, blank: int) -> torch.Tensor:
-        """Per-utterance -log P(y|x), shape (B,), through the fused path (no (B,T,U+1,V) tensor)."""
+    def loss(self, input_audios, tensor_audio_lengths, input_texts, targets, target_lengths, blank: int,
+             reduction: str = "none") -> torch.Tensor:
+        """-log P(y|x) through the fused path (no (B,T,U+1,V) tensor): per utterance, shape (B,) (reduction "none"), or the 0-d
+        "mean" / "sum" over the batch (model.py:39 builds the reference's loss with reduction="mean")."""
         dev = input_audios.device
         t_lens = lengths_to_device(tensor_audio_lengths, dev)
         u_lens = lengths_to_device(target_lengths, dev)
         enc = self.encoder.forward_time_major(input_audios, t_lens)
         dec = self.decoder.forward_time_major(input_texts, u_lens + 1)  # text length = label length + 1 (dataloader.py:39-40)
-        return JointLossFn.apply(enc, dec, self.fc.weight, self.fc.bias, targets, t_lens, u_lens, blank, torch.is_grad_enabled())
+        return JointLossFn.apply(enc, dec, self.fc.weight, self.fc.bias, targets, t_lens, u_lens, blank, torch.is_grad_enabled(), reduction)
 
     @torch.no_grad()
     def recognize_greedy(self, inputs: torch.Tensor, inputs_lengths, blank_token_id: int, max_iters: int = 3,

@@ -457,7 +457,7 @@ class JointLossFn(torch.autograd.Function):
     Under torch.no_grad() (validation_step) no gradient kernel runs and nothing is kept."""
 
     @staticmethod
-    def forward(ctx, enc, dec, W, bias, labels, t_lens, u_lens, blank, want_grad=True):
+    def forward(ctx, enc, dec, W, bias, labels, t_lens, u_lens, blank, want_grad=True, reduction="none"):
         _need_gpu(enc, dec, W, bias, labels, t_lens, u_lens)
         w_param, b_param = W, bias
         enc, dec, W, bias = _f32c(enc, "enc"), _f32c(dec, "dec"), _f32c(W, "fc.weight"), _f32c(bias, "fc.bias")
@@ -483,22 +483,29 @@ class JointLossFn(torch.autograd.Function):
             ctx.save_for_backward(enc, dec, W, bias, labels, t_lens, u_lens, A, Cm, ws)
             ctx.blank = int(blank)
             ctx.w_param, ctx.b_param = w_param, b_param
-        return nll
+        ctx.red_scale = {"none": None, "sum": 1.0, "mean": 1.0 / B}[reduction]
+        if ctx.red_scale is None:
+            return nll
+        out = torch.empty((), device=enc.device, dtype=torch.float32)   # reduction inside the library: no torch arithmetic on the path
+        check(_lib.lib().rnnt_hip_scaled_sum_f32(_addr(nll), B, ctx.red_scale, _addr(out), _stream()), "rnnt_hip_scaled_sum_f32")
+        return out
 
     @staticmethod
     def backward(ctx, g):
         enc, dec, W, bias, labels, t_lens, u_lens, A, Cm, ws = ctx.saved_tensors
         T, B, _ = enc.shape
         U1, V = dec.shape[0], W.shape[0]
-        gvec = _f32c(g.to(torch.float32), "grad of nll")
+        gvec = _f32c(g.to(torch.float32), "grad of the loss")
+        scalar = ctx.red_scale is not None   # reduced loss: ONE upstream scalar, the 1/B of "mean" rides in gscale
         dA, dC = torch.empty_like(A), torch.empty_like(Cm)
         check(_lib.lib().rnnt_hip_joint_loss_bwd(_addr(A), V, B * V, _addr(Cm), V, B * V, _addr(bias), _addr(labels),
-                                                 _addr(t_lens), _addr(u_lens), B, T, U1, V, ctx.blank, 1.0, _addr(gvec),
+                                                 _addr(t_lens), _addr(u_lens), B, T, U1, V, ctx.blank,
+                                                 ctx.red_scale if scalar else 1.0, _addr(gvec), 0 if scalar else 1,
                                                  _addr(dA), _addr(dC), _addr(ws), ws.numel(), _stream()),
               "rnnt_hip_joint_loss_bwd")
         d_enc, d_dec, dW, db = _joint_backward(enc, dec, W, dA, dC, ctx.needs_input_grad[:4],
                                                _direct_grad(ctx.w_param), _direct_grad(ctx.b_param))
-        return d_enc, d_dec, dW, db, None, None, None, None, None
+        return d_enc, d_dec, dW, db, None, None, None, None, None, None
 
 
 class JointLogitsFn(torch.autograd.Function):
