@@ -120,3 +120,36 @@
 
 DEFINE_RNNT_REF(rnnt_loss_ref_f64, double, exp, log1p, fabs, (-INFINITY))
 DEFINE_RNNT_REF(rnnt_loss_ref_f32, float, expf, log1pf, fabsf, (-INFINITY))
+
+/*
+ * CPU build of the C-ABI entry `rnnt_hip_loss_from_logits_fwd_bwd` (include/rnnt_hip.h; it replaces the reference's call
+ * `Warp_RNNTLoss.__call__` at model.py:57): SAME name, SAME argument list, host pointers instead of device pointers; `workspace`,
+ * `workspace_bytes` and `stream` are accepted and ignored.  Tests load this library and librnnt_hip.so side by side and hand both the
+ * same arguments ("a CPU build of the same ABI (the restatement) is exported from a second .so for tests").
+ * Arithmetic: the float64 restatement above, outputs rounded to float once; grad = d(sum_b gscale * nll_b) / d logits.
+ * Returns 0, or -1 (RNNT_ERR_INVALID) on bad arguments / lengths, as the HIP entry does.
+ */
+int rnnt_hip_loss_from_logits_fwd_bwd(const float* logits, const int* labels, const int* t_lens, const int* u_lens, int B, int T,
+                                      int U1, int V, int blank, float gscale, float* nll, float* grad, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  if (!logits || !t_lens || !u_lens || !nll || B < 1 || T < 1 || U1 < 1 || V < 1 || blank < 0 || blank >= V || (U1 > 1 && !labels))
+    return -1;
+  const size_t n = (size_t)B * T * U1 * V;
+  double* z = (double*)malloc(sizeof(double) * n);
+  double* g = grad ? (double*)malloc(sizeof(double) * n) : NULL;
+  double* l = (double*)malloc(sizeof(double) * (size_t)B);
+  if (!z || !l || (grad && !g)) {
+    free(z); free(g); free(l);
+    return -2;
+  }
+  for (size_t i = 0; i < n; ++i) z[i] = (double)logits[i];
+  int rc = rnnt_loss_ref_f64(z, labels, t_lens, u_lens, B, T, U1, V, blank, l, g);
+  if (rc == 0) {
+    for (int b = 0; b < B; ++b) nll[b] = (float)l[b];
+    if (grad)
+      for (size_t i = 0; i < n; ++i) grad[i] = (float)(g[i] * (double)gscale);
+  }
+  free(z); free(g); free(l);
+  return rc == 0 ? 0 : -1;
+}

@@ -384,7 +384,9 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
           const int u = u0 + j;
           if (u > Ub) break;
           const CellS c = crow[u];
-          float g = c.w * expf(a[i] + cs[j] - c.lse);
+          // v_exp_f32 form: |rel err| <~ 3e-7 on a value in [0, 1] (the softmax probability times a path weight <= 1), i.e. an
+          // absolute gradient error ~1e-7 against the 2e-5 the tests allow; ocml expf was 2/3 of this loop's instructions
+          float g = c.w * __expf(a[i] + cs[j] - c.lse);
           if (v == blank) g -= c.cb;
           if (v == yv[j]) g -= c.ce;
           accA[i] += g;

@@ -279,3 +279,37 @@ def test_integration_md_ctypes_stub_runs_verbatim_and_matches_the_oracle():
                                              torch.from_numpy(u_lens).cuda(), 0)
     assert abs(loss.item() - ref_nll.mean()) / ref_nll.mean() < 1e-5
     assert np.abs(grad.cpu().numpy() - ref_grad / B).max() < 2e-5
+
+
+def test_cpu_build_of_the_same_abi_agrees_with_the_hip_library():
+    """the oracle's .so exports `rnnt_hip_loss_from_logits_fwd_bwd` with the SAME argument list (host pointers); both
+    libraries get identical arguments through raw ctypes and must agree."""
+    from oracle import build_oracle
+    from rnntransducer_amd import _lib
+    cpu = ctypes.CDLL(build_oracle.build())
+    hip = ctypes.CDLL(_lib.LIB_PATH)
+    hip.rnnt_hip_joint_loss_workspace_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(3)
+    B, T, U, V = 3, 17, 5, 23
+    z = rng.normal(size=(B, T, U + 1, V)).astype(np.float32)
+    y = rng.integers(1, V, size=(B, U)).astype(np.int32)
+    t_lens, u_lens = np.array([17, 9, 4], np.int32), np.array([5, 3, 0], np.int32)
+    nws = hip.rnnt_hip_joint_loss_workspace_bytes(B, T, U + 1, V)
+
+    def call(lib, to_arg, out_nll, out_grad, ws, stream):
+        p = ctypes.c_void_p
+        rc = lib.rnnt_hip_loss_from_logits_fwd_bwd(p(to_arg(z)), p(to_arg(y)), p(to_arg(t_lens)), p(to_arg(u_lens)), B, T, U + 1, V, 0,
+                                                   ctypes.c_float(0.5), p(out_nll), p(out_grad), p(ws), ctypes.c_size_t(nws), p(stream))
+        assert rc == 0
+    nll_c, grad_c = np.empty(B, np.float32), np.empty_like(z)
+    call(cpu, lambda a: a.ctypes.data, nll_c.ctypes.data, grad_c.ctypes.data, None, None)
+    dev = {id(a): torch.from_numpy(a).cuda() for a in (z, y, t_lens, u_lens)}
+    nll_g, grad_g = torch.empty(B, device="cuda"), torch.empty(B, T, U + 1, V, device="cuda")
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    call(hip, lambda a: dev[id(a)].data_ptr(), nll_g.data_ptr(), grad_g.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nll_g.cpu().numpy(), nll_c, rtol=1e-5)
+    assert np.abs(grad_g.cpu().numpy() - grad_c).max() < 2e-5
+    # the same bad-argument convention on both sides
+    assert cpu.rnnt_hip_loss_from_logits_fwd_bwd(None, None, None, None, 1, 1, 1, 3, 0, ctypes.c_float(1.0), None, None, None, 0, None) == -1
+    assert hip.rnnt_hip_loss_from_logits_fwd_bwd(None, None, None, None, 1, 1, 1, 3, 0, ctypes.c_float(1.0), None, None, None, 0, None) == -1

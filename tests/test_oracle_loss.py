@@ -72,3 +72,21 @@ def test_bad_lengths_rejected():
         rnnt_loss_c(z, np.array([[1]]), [4], [1])
     with pytest.raises(ValueError):
         rnnt_loss_c(z, np.array([[1]]), [3], [2])
+
+
+def test_cpu_build_of_the_c_abi_entry_matches_the_restatement():
+    """oracle/rnnt_loss_ref.c also exports `rnnt_hip_loss_from_logits_fwd_bwd` with the argument list of include/rnnt_hip.h (host
+    pointers): same numbers as rnnt_loss_c on the G3 known-answer vector, gscale applied to the gradient."""
+    import ctypes
+    from oracle import build_oracle
+    lib = ctypes.CDLL(build_oracle.build())
+    z = np.ascontiguousarray(G3_LOGITS[None].astype(np.float32)) if G3_LOGITS.ndim == 3 else np.ascontiguousarray(G3_LOGITS.astype(np.float32))
+    B, T, U1, V = z.shape
+    y = np.array([[1, 2]], np.int32)
+    t_lens, u_lens = np.array([T], np.int32), np.array([U1 - 1], np.int32)
+    nll, grad = np.empty(B, np.float32), np.empty_like(z)
+    p = ctypes.c_void_p
+    rc = lib.rnnt_hip_loss_from_logits_fwd_bwd(p(z.ctypes.data), p(y.ctypes.data), p(t_lens.ctypes.data), p(u_lens.ctypes.data), B, T, U1, V, 0,
+                                               ctypes.c_float(2.0), p(nll.ctypes.data), p(grad.ctypes.data), None, ctypes.c_size_t(0), None)
+    assert rc == 0 and abs(nll[0] - 4.495666) < 5e-6
+    np.testing.assert_allclose(grad, 2.0 * np.asarray(G3_GRAD, np.float32).reshape(grad.shape), atol=2e-6)
