@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RNNT_HIP_ABI_VERSION 2
+#define RNNT_HIP_ABI_VERSION 3
 
 #define RNNT_OK 0
 #define RNNT_ERR_INVALID (-1)   /* bad argument (dims, alignment, null pointer)            */
@@ -129,6 +129,22 @@ int rnnt_hip_gemm_hp(const void* A, const uint32_t* a_amax, const void* B, const
                      float* C, int64_t ldc, const float* bias, uint32_t flags, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* Up to 4 such products in ONE queue-driven launch: 256 resident workgroups draw (problem, tile, K-split) units until none is left
+ * (one launch tail instead of one per product).  xcd_skip: bit x set = workgroups that find themselves on XCD x leave at once, the
+ * other XCDs do all the work — for products that run on a second stream beside a persistent recurrence (rnnt_lstm_bwd_desc.phase).
+ * workspace: rnnt_hip_gemm_hp_grouped_workspace_bytes(...) bytes, 256-byte aligned (queue counters + deterministic split-K slabs).
+ * Used internally by rnnt_hip_lstm_bwd for dW_ih / dW_hh; exposed for tests. */
+typedef struct rnnt_hp_problem {
+  const void* A; const uint32_t* a_amax;   /* (M x K) planes + row maxima */
+  const void* B; const uint32_t* b_amax;   /* (N x K) */
+  int64_t M, N, K;
+  float* C; int64_t ldc;
+  uint32_t flags;                          /* RNNT_GEMM_ACCUM */
+} rnnt_hp_problem;
+size_t rnnt_hip_gemm_hp_grouped_workspace_bytes(const rnnt_hp_problem* problems, int32_t n);
+int rnnt_hip_gemm_hp_grouped(const rnnt_hp_problem* problems, int32_t n, uint32_t xcd_skip, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LSTM layer (both directions in one launch), packed-sequence semantics.
  * Replaces torch.nn.LSTM over a PackedSequence + sort/pack/unpack/unsort:
@@ -194,7 +210,19 @@ typedef struct rnnt_lstm_bwd_desc {
                        * destination that receives the same values as db (grad b_hh == grad b_ih), or NULL */
   int32_t accumulate; /* 0: dw_ih / dw_hh / db / db_hh are written; 1: added to (the outputs are views of a flat gradient
                        * buffer that autograd would otherwise `+=` into with one extra kernel per parameter) */
+  int32_t phase;      /* RNNT_LSTM_BWD_ALL (0): everything on `stream`.  The two halves can also be issued separately so that a
+                       * caller overlaps the weight gradients of layer l with the recurrence of layer l-1 (autograd needs only dx
+                       * to go on): RNNT_LSTM_BWD_RECUR (1) = reverse-time recurrence (gates -> dG in place) + dx;
+                       * RNNT_LSTM_BWD_WEIGHTS (2) = dw_ih / dw_hh / db / db_hh from the dG that phase 1 left in `gates`, on any
+                       * stream ordered after phase 1, with the SAME descriptor and workspace (which phase 1 of another layer must
+                       * not reuse before phase 2 is done: alternate two workspaces). */
+  int32_t beside_recurrence; /* phase 2 only, a hint: 1 = a recurrence of the same (B,H,D) runs concurrently on another stream; the
+                       * big products then leave the XCDs that recurrence occupies alone (its workgroups exchange through their
+                       * XCD's L2) and run as one queue-driven launch on the others.  Results do not depend on it. */
 } rnnt_lstm_bwd_desc;
+#define RNNT_LSTM_BWD_ALL 0
+#define RNNT_LSTM_BWD_RECUR 1
+#define RNNT_LSTM_BWD_WEIGHTS 2
 
 int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* d, void* stream);
 /* reads back the persistent kernels' status word from a workspace (synchronises `stream`);

@@ -10,6 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librnnt_hip.so")
+ABI_VERSION = 3   # RNNT_HIP_ABI_VERSION of include/rnnt_hip.h
 
 GEMM_GELU_A, GEMM_GELU_B, GEMM_ACCUM, GEMM_MUL_DGELU, GEMM_EXACT_F32 = 1, 2, 4, 8, 16
 CELL_LSTM, CELL_GRU, CELL_RNN_TANH, CELL_RNN_RELU = 0, 1, 2, 3
@@ -38,7 +39,13 @@ class LstmDesc(C.Structure):
 
 class LstmBwdDesc(C.Structure):
     _fields_ = [("f", LstmDesc), ("dy", C.c_void_p), ("dx", C.c_void_p), ("dw_ih", C.c_void_p * 2),
-                ("dw_hh", C.c_void_p * 2), ("db", C.c_void_p * 2), ("db_hh", C.c_void_p * 2), ("accumulate", c_i32)]
+                ("dw_hh", C.c_void_p * 2), ("db", C.c_void_p * 2), ("db_hh", C.c_void_p * 2), ("accumulate", c_i32), ("phase", c_i32),
+                ("beside_recurrence", c_i32)]
+
+
+class HpProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("a_amax", C.c_void_p), ("B", C.c_void_p), ("b_amax", C.c_void_p), ("M", c_i64), ("N", c_i64),
+                ("K", c_i64), ("C", C.c_void_p), ("ldc", c_i64), ("flags", C.c_uint32)]
 
 
 DECODE_MAX_LAYERS = 8
@@ -74,6 +81,8 @@ SYMBOLS = {
     "rnnt_hip_gemm_hp_workspace_bytes": (C.c_size_t, [c_i64, c_i64, c_i64]),
     "rnnt_hip_gemm_hp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, c_i64, C.c_void_p,
                                   C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnnt_hip_gemm_hp_grouped_workspace_bytes": (C.c_size_t, [C.POINTER(HpProblem), c_i32]),
+    "rnnt_hip_gemm_hp_grouped": (C.c_int, [C.POINTER(HpProblem), c_i32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_lstm_workspace_bytes": (C.c_size_t, [c_i32] * 5),
     "rnnt_hip_lstm_max_batch": (c_i32, [c_i32, c_i32, c_i32]),
     "rnnt_hip_lstm_fwd": (C.c_int, [C.POINTER(LstmDesc), C.c_void_p]),
@@ -135,6 +144,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if handle.rnnt_hip_version() != ABI_VERSION:   # a stale build would read the descriptors with the wrong layout
+            raise RnntHipError(f"{LIB_PATH} reports ABI version {handle.rnnt_hip_version()}, this package binds version {ABI_VERSION}: "
+                               "rebuild it with `python -m rnntransducer_amd.csrc.build`")
         _lib = handle
     return _lib
 

@@ -53,6 +53,18 @@ size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N, int64_t K, float* C,
             int64_t c_div, int64_t c_so, int64_t c_si, const float* bias, unsigned flags, void* workspace, size_t workspace_bytes,
             hipStream_t s);
+// several NT products in ONE queue-driven launch (workgroups on the XCDs of `xcd_skip` leave at once): the weight-gradient
+// products that run beside the next layer's recurrence.  `counter`: 8 device words (one queue per XCD), zeroed here.
+struct HpProblem {
+  const void* A; const uint32_t* a_amax; const void* B; const uint32_t* b_amax;
+  int64_t M, N, K;
+  float* C; int64_t ldc;
+  unsigned flags;
+};
+constexpr int HP_GROUP_MAX = 4;
+size_t hp_gemm_grouped_workspace_bytes(const int64_t* MN, int n);   // MN[i] = M_i * N_i
+int hp_gemm_grouped(const HpProblem* pr, int n, unsigned xcd_skip, unsigned* counter, void* workspace, size_t workspace_bytes,
+                    hipStream_t s);
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // gelu_tanh and its derivative (torch.nn.GELU(approximate="tanh"), networks/transducer.py:38)

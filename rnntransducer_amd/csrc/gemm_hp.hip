@@ -190,13 +190,11 @@ __device__ __forceinline__ int hp_xcd_remap(int bid, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
-__global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+// one 256 x 256 output tile (`bid` = column-major tile index) over K-tiles [z * kt_per_split, ...) of problem p
+__device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, const int z, char* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int bid = hp_xcd_remap(blockIdx.x, ntiles);
   const int m0 = (bid % p.tiles_m) * HP_BM, n0 = (bid / p.tiles_m) * HP_BN;
 
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, (int)p.a_bytes, HP_RSRC);
@@ -236,7 +234,7 @@ __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int kt0 = blockIdx.y * p.kt_per_split;
+  const int kt0 = z * p.kt_per_split;
   const int nk = min(p.nkt - kt0, p.kt_per_split);
 
   stage(0, kt0);
@@ -285,7 +283,7 @@ __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
 
   // epilogue: D block (i, j): lane -> rows 4*(lane>>4) + reg, column lane&15
   const int mode = p.splits > 1 ? 0 : ((p.flags & RNNT_GEMM_ACCUM) ? 2 : 1);  // uniform: slab | store | accumulate
-  float* slab = p.splits > 1 ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
+  float* slab = p.splits > 1 ? p.slab + (long)z * p.M * p.N : nullptr;
   float bias_v[4], sb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -315,6 +313,63 @@ __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
         const int n = n0 + wc * 64 + j * 16 + (lane & 15);
         if (mok && n < p.N) crow[n] = acc[i][j][reg] * sa * sb[j] + bias_v[j] + old[j];
       }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  hp_tile256(p, hp_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), blockIdx.y, lds);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Grouped, queue-driven form for work that runs BESIDE a persistent recurrence (the weight-gradient products of layer l under
+// the reverse-time recurrence of layer l-1, lstm.hip): up to 4 problems in one launch, 256 resident workgroups that draw
+// (problem, tile, K-split) units from one atomic counter until it runs dry.  `xcd_skip`: bit x set = workgroups that find
+// themselves on XCD x leave at once (the recurrence owns those XCDs: its workgroups exchange through that XCD's L2 and must not
+// share SIMDs or L2 with a GEMM); the remaining XCDs do all units.  Which workgroup computes which unit varies from run to run,
+// the arithmetic of a unit does not: results are bitwise reproducible.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int HPQ_MAX = 4;
+struct HpGemmQ {
+  HpGemmK prob[HPQ_MAX];
+  int unit_end[HPQ_MAX];   // prefix sums of tiles * splits
+  int nprob;
+  unsigned xcd_skip;
+  unsigned* counter;       // 8 words (one queue per XCD), zeroed before the launch
+};
+
+// Unit u of a problem: n-tile fastest, then K-split, then m-tile — neighbours in the queue share the A panel (same rows, same
+// K range) and, every tiles_n units, the B panels.  Every participating XCD owns one contiguous share of the units (its 32
+// workgroups walk it front to back: what they have in flight at any time re-uses a handful of panels through that XCD's L2;
+// drawing from ONE queue across XCDs measured 2.95 ms against a 2.0 ms estimate for a c2 layer: every tile fetched both panels
+// from HBM); an XCD that runs dry takes units from the others' shares.
+__global__ void __launch_bounds__(512, 1) gemm_hpq_kernel(const HpGemmQ q) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  if ((q.xcd_skip >> xcc) & 1u) return;
+  const unsigned allow = ~q.xcd_skip & 0xffu;
+  const int nq = __builtin_popcount(allow);
+  const int mine = __builtin_popcount(allow & ((1u << xcc) - 1u));
+  int* next = reinterpret_cast<int*>(lds + 2 * HP_STAGE);
+  const int total = q.unit_end[q.nprob - 1];
+  for (int hop = 0; hop < nq; ++hop) {
+    const int qi = (mine + hop) % nq;
+    const int lo = (int)((long)total * qi / nq), hi = (int)((long)total * (qi + 1) / nq);
+    while (true) {
+      if (threadIdx.x == 0) *next = lo + (int)atomicAdd(q.counter + qi, 1u);
+      __syncthreads();
+      const int u = __builtin_amdgcn_readfirstlane(*next);
+      __syncthreads();
+      if (u >= hi) break;
+      int pi = 0;
+      while (u >= q.unit_end[pi]) ++pi;
+      const HpGemmK& p = q.prob[pi];
+      const int local = u - (pi ? q.unit_end[pi - 1] : 0);
+      const int tn = local % p.tiles_n, z = (local / p.tiles_n) % p.splits, tm = local / (p.tiles_n * p.splits);
+      hp_tile256(p, tn * p.tiles_m + tm, z, lds);
     }
   }
 }
@@ -552,6 +607,80 @@ int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t
   return RNNT_OK;
 }
 
+constexpr int HPQ_SPLIT_CAP = 8;
+size_t hp_gemm_grouped_workspace_bytes(const int64_t* MN, int n) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += align_up((size_t)HPQ_SPLIT_CAP * (size_t)MN[i] * 4, 256);
+  return total;
+}
+
+int hp_gemm_grouped(const HpProblem* pr, int n, unsigned xcd_skip, unsigned* counter, void* workspace, size_t workspace_bytes,
+                    hipStream_t s) {
+  RNNT_CHECK_ARG(pr && n >= 1 && n <= HPQ_MAX && counter, "gemm_hp grouped: 1..%d problems and a counter word", HPQ_MAX);
+  RNNT_CHECK_ARG((xcd_skip & 0xffu) != 0xffu, "gemm_hp grouped: xcd_skip leaves no XCD");
+  HpGemmQ q = {};
+  q.nprob = n; q.xcd_skip = xcd_skip; q.counter = counter;
+  int xcds = 0;
+  for (int x = 0; x < 8; ++x) xcds += !((xcd_skip >> x) & 1u);
+  const long workers = 32l * xcds;
+  long total_kt = 0;
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const HpProblem& a = pr[i];
+    RNNT_CHECK_ARG(a.A && a.B && a.C && a.a_amax && a.b_amax, "gemm_hp grouped: null operand (problem %d)", i);
+    RNNT_CHECK_ARG(a.M >= 1 && a.N >= 1 && a.K >= 1 && a.M < (1ll << 31) && a.N < (1ll << 31) && a.K < (1ll << 31) && a.ldc >= a.N,
+                   "gemm_hp grouped: bad dims (problem %d)", i);
+    RNNT_CHECK_ARG(((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 127) == 0, "gemm_hp grouped: planes must be 128-byte aligned");
+    HpGemmK& k = q.prob[i];
+    k.M = (int)a.M; k.N = (int)a.N; k.nkt = (int)ceil_div(a.K, HP_BK);
+    const size_t ab = hp_plane_bytes(a.M, a.K), bb = hp_plane_bytes(a.N, a.K);
+    RNNT_CHECK_ARG(ab < (1ull << 32) && bb < (1ull << 32), "gemm_hp grouped: an operand exceeds the 4 GB a buffer resource addresses");
+    k.A = (const char*)a.A; k.a_pitch = (unsigned)k.nkt * 128u; k.a_bytes = (unsigned)ab;
+    k.B = (const char*)a.B; k.b_pitch = (unsigned)k.nkt * 128u; k.b_bytes = (unsigned)bb;
+    k.a_amax = a.a_amax; k.b_amax = a.b_amax;
+    k.C = a.C; k.c_div = 1; k.c_so = a.ldc; k.c_si = 0;
+    k.bias = nullptr; k.flags = a.flags;
+    k.tiles_m = (int)ceil_div(a.M, HP_BM); k.tiles_n = (int)ceil_div(a.N, HP_BN);
+    total_kt += (long)k.tiles_m * k.tiles_n * k.nkt;
+    flops += 2.0 * (double)a.M * (double)a.N * (double)a.K;
+  }
+  // units of (about) equal length, four per resident workgroup: the queue levels whatever imbalance remains
+  long chunk = ceil_div(total_kt, 4 * workers);
+  if (chunk < 32) chunk = 32;
+  size_t off = 0;
+  int units = 0;
+  for (int i = 0; i < n; ++i) {
+    HpGemmK& k = q.prob[i];
+    long splits = ceil_div(k.nkt, chunk);
+    if (splits > HPQ_SPLIT_CAP) splits = HPQ_SPLIT_CAP;
+    const size_t per = (size_t)k.M * k.N * 4;
+    while (splits > 1 && (!workspace || off + align_up((size_t)splits * per, 256) > workspace_bytes)) --splits;
+    k.kt_per_split = (int)ceil_div(k.nkt, splits);
+    k.splits = (int)ceil_div(k.nkt, k.kt_per_split);
+    k.slab = k.splits > 1 ? reinterpret_cast<float*>((char*)workspace + off) : nullptr;
+    if (k.splits > 1) off += align_up((size_t)k.splits * per, 256);
+    units += k.tiles_m * k.tiles_n * k.splits;
+    q.unit_end[i] = units;
+  }
+  RNNT_CHECK_HIP(hipMemsetAsync(counter, 0, 32, s));
+  const int lds = 2 * HP_STAGE + 16;
+  RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hpq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  {
+    ProfScope prof(RNNT_K_GEMM_HP, flops, s);
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    hipLaunchKernelGGL(gemm_hpq_kernel, dim3(!xcd_skip && units < cus ? units : cus), dim3(512), lds, s, q);   // with skipped XCDs: one per CU, an eighth lands on each XCD
+    RNNT_CHECK_LAUNCH();
+    for (int i = 0; i < n; ++i)
+      if (q.prob[i].splits > 1) {
+        const long blocks = ceil_div((long)q.prob[i].M * q.prob[i].N, 256);
+        hipLaunchKernelGGL(hp_splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, q.prob[i]);
+        RNNT_CHECK_LAUNCH();
+      }
+  }
+  return RNNT_OK;
+}
+
 }  // namespace rnnt
 
 using namespace rnnt;
@@ -587,4 +716,27 @@ extern "C" int rnnt_hip_gemm_hp(const void* A, const uint32_t* a_amax, const voi
                                 size_t workspace_bytes, void* stream) {
   RNNT_CHECK_ARG(ldc >= N, "gemm_hp: ldc < N");
   return hp_gemm(A, a_amax, B, b_amax, M, N, K, C, 1, ldc, 0, bias, flags, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static_assert(sizeof(rnnt_hp_problem) == sizeof(HpProblem), "rnnt_hp_problem mirrors HpProblem");
+
+extern "C" size_t rnnt_hip_gemm_hp_grouped_workspace_bytes(const rnnt_hp_problem* problems, int32_t n) {
+  if (!problems || n < 1 || n > HP_GROUP_MAX) return 0;
+  int64_t mn[HP_GROUP_MAX];
+  for (int i = 0; i < n; ++i) mn[i] = problems[i].M * problems[i].N;
+  return 256 + hp_gemm_grouped_workspace_bytes(mn, n);
+}
+
+extern "C" int rnnt_hip_gemm_hp_grouped(const rnnt_hp_problem* problems, int32_t n, uint32_t xcd_skip, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  RNNT_CHECK_ARG(problems && n >= 1 && n <= HP_GROUP_MAX, "gemm_hp grouped: 1..%d problems", HP_GROUP_MAX);
+  RNNT_CHECK_ARG(workspace && workspace_bytes >= 256 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+                 "gemm_hp grouped: workspace of >= 256 bytes, 256-byte aligned");
+  HpProblem pr[HP_GROUP_MAX];
+  for (int i = 0; i < n; ++i) {
+    const rnnt_hp_problem& a = problems[i];
+    pr[i] = HpProblem{a.A, a.a_amax, a.B, a.b_amax, a.M, a.N, a.K, a.C, a.ldc, a.flags};
+  }
+  return hp_gemm_grouped(pr, n, xcd_skip, reinterpret_cast<unsigned*>(workspace), (char*)workspace + 256, workspace_bytes - 256,
+                         (hipStream_t)stream);
 }

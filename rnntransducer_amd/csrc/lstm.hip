@@ -1572,6 +1572,9 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
       const size_t h1 = hp_gemm_workspace_bytes(N4, I, M), h2 = hp_gemm_workspace_bytes(4 * H, H, M);
       if (h1 > sc) sc = h1;
       if (h2 > sc) sc = h2;
+      const int64_t mn[3] = {N4 * I, (int64_t)4 * H * H, (int64_t)4 * H * H};   // the grouped launch keeps all slabs at once
+      const size_t h3 = hp_gemm_grouped_workspace_bytes(mn, 1 + D);
+      if (h3 > sc) sc = h3;
     }
     w.scratch_bytes = sc;
     w.scratch = take(sc);
@@ -1850,10 +1853,15 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   RNNT_CHECK_ARG(d->x_sb == I && d->x_st == (int64_t)B * I, "lstm_bwd: x must be time-major contiguous (T,B,I)");
   for (int k = 0; k < D; ++k) RNNT_CHECK_ARG(bd->dw_ih[k] && bd->dw_hh[k] && bd->db[k], "lstm_bwd: null gradient output");
   hipStream_t s = (hipStream_t)stream;
+  RNNT_CHECK_ARG(bd->phase >= RNNT_LSTM_BWD_ALL && bd->phase <= RNNT_LSTM_BWD_WEIGHTS, "lstm_bwd: phase must be 0, 1 or 2");
+  // phase 1 = steps 1-2 (the chain autograd waits for), phase 2 = steps 3-5 (weight / bias gradients: any stream ordered after phase 1)
+  const bool do_recur = bd->phase != RNNT_LSTM_BWD_WEIGHTS, do_weights = bd->phase != RNNT_LSTM_BWD_RECUR;
 
   // 1. reverse-time recurrence: gates (activated) -> dG in place
-  RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, w.sync_bytes, s));
-  RNNT_CHECK_HIP(hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+  if (do_recur) {
+    RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, w.sync_bytes, s));
+    RNNT_CHECK_HIP(hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+  }
   LstmK k;
   fill_kernel_args(d, pl, w, &k);
   k.dy = bd->dy;
@@ -1865,6 +1873,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   };
   bool fused_db = false, colmax_done = false;
   int db_rows = 0;
+  unsigned xcd_skip = 0;
   if (make_plan3(d->B, d->H, d->D, cus, true, &p2)) {
     adopt(p2);
     fused_db = true;
@@ -1888,11 +1897,18 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
         const int64_t Mr = (int64_t)T * B, N4r = (int64_t)D * 4 * H;
         k.colmax = w.hp_amax + Mr + N4r + Mr;
         k.colmax_h = w.hp_amax + 2 * Mr + 2 * N4r + 2 * I + (int64_t)D * H;
-        RNNT_CHECK_HIP(hipMemsetAsync(k.colmax, 0, (size_t)N4r * 4, s));
-        RNNT_CHECK_HIP(hipMemsetAsync(k.colmax_h, 0, (size_t)N4r * 4, s));
+        if (do_recur) {
+          RNNT_CHECK_HIP(hipMemsetAsync(k.colmax, 0, (size_t)N4r * 4, s));
+          RNNT_CHECK_HIP(hipMemsetAsync(k.colmax_h, 0, (size_t)N4r * 4, s));
+        }
         colmax_done = true;
       }
-      rc = lstm5_bwd_launch(k, p2, d->cell, s);
+      if (do_recur) rc = lstm5_bwd_launch(k, p2, d->cell, s);
+      // the weight-gradient products of THIS layer may run beside the recurrence of the next one (same shape): that one sits on
+      // XCDs 0 .. D*G-1 (launch_persistent2's stride-8 placement), the products keep to the others
+      if (bd->beside_recurrence && D * p2.G <= 4 && p2.NC <= 64) xcd_skip = (1u << (D * p2.G)) - 1u;
+    } else if (!do_recur) {
+      // phase 2: nothing to launch here
     } else if (p2.MB == 5) {  // H = 640: own 80 gate columns (3 k-steps), 48 output blocks over 8 waves
 #define LAUNCH_V45_C(BQ_, C) rc = launch_persistent2(lstm_bwd4_kernel<6, BQ_, C, 8, 5, 1>, k, p2, p2.lds_bwd + 8 * 1 * 3 * 3 * 1024, s, "lstm_bwd4", 512)
 #define LAUNCH_V45_B(C)                           \
@@ -1936,9 +1952,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
 #undef LAUNCH_V4_C
   } else if (make_plan2(d->B, d->H, d->D, cus, &p2)) {
     adopt(p2);
-    DISPATCH_HS_BQ(lstm_bwd2_kernel, d->cell, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
+    if (do_recur) DISPATCH_HS_BQ(lstm_bwd2_kernel, d->cell, p2, k, p2, p2.lds_bwd, s, "lstm_bwd2");
   } else if (d->cell == RNNT_CELL_LSTM) {
-    DISPATCH_MT_NT(lstm_bwd_kernel, pl, k, pl, pl.lds_bwd, s, "lstm_bwd");
+    if (do_recur) DISPATCH_MT_NT(lstm_bwd_kernel, pl, k, pl, pl.lds_bwd, s, "lstm_bwd");
   } else {
     set_error("rnn: GRU / Elman cells need the grouped decomposition; B=%d H=%d does not fit", d->B, d->H);
     rc = RNNT_ERR_UNSUPPORTED;
@@ -1954,14 +1970,15 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   uint32_t* a_x = w.hp ? a_w + I : nullptr;
   uint32_t* a_y = w.hp ? a_x + I : nullptr;
   if (w.hp) {  // half-pair planes of dG in both orientations (gemm_hp.hip is NT-only: transposed operands are materialised)
-    if (hp_in && bd->dx)
+    if (do_recur && hp_in && bd->dx)
       if ((rc = hp_split(d->gates, M, N4, N4, a_dgr, w.hp_dg, s))) return rc;
-    if (!colmax_done)
+    if (do_weights && !colmax_done)
       if ((rc = hp_colmax(d->gates, M, N4, N4, a_dgc, s))) return rc;
-    if ((rc = hp_split_t(d->gates, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
+    if (do_weights)
+      if ((rc = hp_split_t(d->gates, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
   }
   // 2. dX = dG . W_ih'   (needs the permuted weights: rebuild them, the forward copy may have been overwritten)
-  if (bd->dx) {
+  if (do_recur && bd->dx) {
     const long per = (long)4 * H * I;
     hipLaunchKernelGGL(permute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, d->w_ih[0],
                        D > 1 ? d->w_ih[1] : d->w_ih[0], H, I, ngate, w.wp);
@@ -1979,12 +1996,19 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
     }
   }
+  if (!do_weights) return RNNT_OK;
+  // All three weight-gradient products on the half-pair path (LSTM / Elman) beside a recurrence: their operand planes first, then
+  // ONE queue-driven launch (gemm_hp.hip) that stays off the recurrence's XCDs.
+  // (alone on the device three launches are faster: 1.13 vs 1.29 ms for a c2 layer, tools/gemm_hpq_bench.py — the queue form is for
+  // the overlapped case, where it keeps off the recurrence's XCDs)
+  const bool grouped = w.hp && hp_in && T > 1 && !gru && D <= 2 && (xcd_skip != 0u || getenv("RNNT_GEMM_HP_GROUP")) && !getenv("RNNT_GEMM_HP_NO_GROUP");
   // 3. dW_ih' = dG^T . X  (both directions at once), un-permute rows into torch layout
   {
     if (hp_in) {
       if ((rc = hp_colmax(d->x, M, I, I, a_x, s))) return rc;
       if ((rc = hp_split_t(d->x, I, M, I, M, 0, a_x, w.hp_x, s))) return rc;     // X^T: (I, contraction T*B)
-      if ((rc = hp_gemm(w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, M, w.wp, 1, I, 0, nullptr, 0, w.scratch, w.scratch_bytes, s))) return rc;
+      if (!grouped)
+        if ((rc = hp_gemm(w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, M, w.wp, 1, I, 0, nullptr, 0, w.scratch, w.scratch_bytes, s))) return rc;
     } else {
       rnnt_gemm_desc g = {};
       g.M = N4; g.N = I; g.K = M;
@@ -1994,10 +2018,12 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       g.workspace = w.scratch; g.workspace_bytes = w.scratch_bytes;
       if ((rc = rnnt_hip_gemm_f32(&g, s))) return rc;
     }
-    const long per = (long)4 * H * I;
-    hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per, ngate,
-                       bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0], acc);
-    RNNT_CHECK_LAUNCH();
+    if (!grouped) {
+      const long per = (long)4 * H * I;
+      hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per, ngate,
+                         bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0], acc);
+      RNNT_CHECK_LAUNCH();
+    }
   }
   // 4. dW_hh'[d] = sum_t dG[t]^T . h_prev(t): time-shifted views of dG and y (padded frames are zero in both)
   if (w.hp && T > 1) {
@@ -2007,14 +2033,28 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       else if ((rc = hp_colmax(ghid, M, N4, N4, a_dgc, s))) return rc;
       if ((rc = hp_split_t(ghid, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
     }
+    HpProblem pr[HP_GROUP_MAX];
+    int npr = 0;
+    if (grouped) pr[npr++] = HpProblem{w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, M, w.wp, I, 0u};
     for (int dir = 0; dir < D; ++dir) {
       // h_prev of frame t is y[t-1] (forward direction) / y[t+1] (reverse): plane row j, index k = y[k -/+ B][dir*H + j], zero outside
       char* yt = w.hp_yt + (size_t)dir * hp_plane_bytes(H, M);
       if ((rc = hp_split_t(d->y + (int64_t)dir * H, H, M, (int64_t)D * H, M, dir == 0 ? -B : B, a_y + (int64_t)dir * H, yt, s))) return rc;
       const char* ag = w.hp_dgt + (size_t)dir * 4 * H * (size_t)ceil_div(M, 32) * 128;
+      if (grouped) {
+        pr[npr++] = HpProblem{ag, a_dgc + (int64_t)dir * 4 * H, yt, a_y + (int64_t)dir * H, 4 * H, H, M, w.dwhh + (int64_t)dir * 4 * H * H, H, 0u};
+        continue;
+      }
       if ((rc = hp_gemm(ag, a_dgc + (int64_t)dir * 4 * H, yt, a_y + (int64_t)dir * H, 4 * H, H, M, w.dwhh + (int64_t)dir * 4 * H * H, 1, H, 0,
                         nullptr, 0, w.scratch, w.scratch_bytes, s)))
         return rc;
+    }
+    if (grouped) {
+      if ((rc = hp_gemm_grouped(pr, npr, xcd_skip, w.flags + 8, w.scratch, w.scratch_bytes, s))) return rc;
+      const long per = (long)4 * H * I;
+      hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per, ngate,
+                         bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0], acc);
+      RNNT_CHECK_LAUNCH();
     }
   } else
   for (int dir = 0; dir < D; ++dir) {

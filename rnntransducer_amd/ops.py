@@ -6,6 +6,7 @@ All internal activations are TIME-MAJOR (T,B,F): one LSTM step touches one conti
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -165,6 +166,30 @@ def gemm_hp(a: HpTensor, b: HpTensor, out: Optional[torch.Tensor] = None, bias: 
     check(_lib.lib().rnnt_hip_gemm_hp(_addr(a.planes), _addr(a.amax), _addr(b.planes), _addr(b.amax), M, N, K, _addr(out), N, _addr(bias),
                                       GEMM_ACCUM if accumulate else 0, _addr(ws), nws, _stream()), "rnnt_hip_gemm_hp")
     return out
+
+
+def gemm_hp_grouped(pairs, outs=None, accumulate: bool = False, xcd_skip: int = 0):
+    """[C_i (M_i, N_i) [+]= A_i . B_i^T] for up to 4 (A, B) pairs of hp operands in ONE queue-driven launch; `xcd_skip`: bit mask of
+    XCDs whose workgroups leave at once (the launch then runs on the other XCDs only)."""
+    n = len(pairs)
+    if not 1 <= n <= 4:
+        raise ValueError("1..4 products per grouped launch")
+    pr = (_lib.HpProblem * n)()
+    res = []
+    for i, (a, b) in enumerate(pairs):
+        if a.K != b.K:
+            raise ValueError(f"contraction lengths differ: {a.K} vs {b.K}")
+        out = outs[i] if outs is not None else torch.empty(a.rows, b.rows, device=a.planes.device, dtype=torch.float32)
+        if tuple(out.shape) != (a.rows, b.rows) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError(f"out[{i}] must be a contiguous float32 ({a.rows}, {b.rows}) tensor")
+        pr[i].A, pr[i].a_amax, pr[i].B, pr[i].b_amax = _addr(a.planes), _addr(a.amax), _addr(b.planes), _addr(b.amax)
+        pr[i].M, pr[i].N, pr[i].K, pr[i].C, pr[i].ldc = a.rows, b.rows, a.K, _addr(out), b.rows
+        pr[i].flags = GEMM_ACCUM if accumulate else 0
+        res.append(out)
+    nws = _lib.lib().rnnt_hip_gemm_hp_grouped_workspace_bytes(pr, n)
+    ws = torch.empty(nws, device=res[0].device, dtype=torch.uint8)
+    check(_lib.lib().rnnt_hip_gemm_hp_grouped(pr, n, int(xcd_skip), _addr(ws), nws, _stream()), "rnnt_hip_gemm_hp_grouped")
+    return res
 
 
 def colsum(X: torch.Tensor, M: int, N: int, ld: Optional[int] = None, into: Optional[torch.Tensor] = None):
@@ -371,6 +396,15 @@ class LstmStackFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * len(weights)
         targets = [_direct_grad(p) for p in ctx.params]
         direct = all(t is not None for t in targets)  # all-or-nothing per stack: one accumulate flag per launch
+        # Only dx is on the chain to the layer below: the weight / bias gradients of layer l (phase 2 of rnnt_hip_lstm_bwd) go to a
+        # second stream and run beside the reverse-time recurrence of layer l-1 (phase 1), which leaves most of the chip idle.
+        # Two workspaces alternate by layer parity so that phase 1 of layer l-1 never touches what phase 2 of layer l still reads.
+        overlap = L >= 2 and not os.environ.get("RNNT_LSTM_NO_OVERLAP")
+        main = torch.cuda.current_stream()
+        side = _side_stream(dy.device) if overlap else None
+        wss = [ctx.ws, torch.empty_like(ctx.ws)] if overlap else [ctx.ws, ctx.ws]
+        side_done: dict = {}
+        keep = []   # tensors phase 2 reads or writes on the side stream: held until the streams have joined
         dx = None
         for layer in range(L - 1, -1, -1):
             x_l, y_l, gates, cst, p = ctx.saved[layer]
@@ -379,7 +413,7 @@ class LstmStackFn(torch.autograd.Function):
             bd = LstmBwdDesc()
             aux = torch.empty_like(gates) if cell == 1 else None
             _fill_lstm_desc(bd.f, T, B, I, H, D, ctx.lens, x_l, wl, y_l, y_l if p > 0 else None, p, seed + layer, gates,
-                            cst, ctx.ws, cell, aux)
+                            cst, wss[layer % 2], cell, aux)
             bd.dy = _addr(dy)
             need_dx = layer > 0 or ctx.x_needs_grad
             dx = torch.empty(T, B, I, device=dy.device, dtype=torch.float32) if need_dx else None
@@ -398,10 +432,36 @@ class LstmStackFn(torch.autograd.Function):
                 bd.dw_ih[k], bd.dw_hh[k], bd.db[k] = _addr(dw_ih), _addr(dw_hh), _addr(db)
                 bd.db_hh[k] = _addr(db_hh) if cell == 1 else None
                 grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = dw_ih, dw_hh, db, db_hh
-            check(_lib.lib().rnnt_hip_lstm_bwd(C.byref(bd), _stream()), "rnnt_hip_lstm_bwd")
+            if not overlap:
+                check(_lib.lib().rnnt_hip_lstm_bwd(C.byref(bd), main.cuda_stream), "rnnt_hip_lstm_bwd")
+                dy = dx
+                continue
+            if layer + 2 in side_done:   # this layer's workspace was last read by phase 2 of layer + 2
+                main.wait_event(side_done[layer + 2])
+            bd.phase = 1
+            check(_lib.lib().rnnt_hip_lstm_bwd(C.byref(bd), main.cuda_stream), "rnnt_hip_lstm_bwd (recurrence + dx)")
+            side.wait_event(main.record_event())
+            bd.phase, bd.beside_recurrence = 2, 1 if layer > 0 else 0
+            check(_lib.lib().rnnt_hip_lstm_bwd(C.byref(bd), side.cuda_stream), "rnnt_hip_lstm_bwd (weight gradients)")
+            side_done[layer] = side.record_event()
+            keep.append((aux, dy, dx))
             dy = dx
+        if overlap:
+            main.wait_stream(side)   # everything below (autograd's accumulation, the optimizer, frees) is ordered after phase 2
+        del keep
         ctx.saved = None  # release the stash
         return (dx if ctx.x_needs_grad else None, None, None, None, None, None, None, None, None, *grads)
+
+
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """One extra stream per device for work that overlaps the persistent recurrences (created once, reused)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
 
 
 def lstm_check(ws: torch.Tensor) -> None:

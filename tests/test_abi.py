@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in rnnt_hip.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert _lib.lib().rnnt_hip_version() == 2
+    assert _lib.lib().rnnt_hip_version() == 3
 
 
 def test_argument_validation_happens_before_any_device_work():

@@ -254,3 +254,38 @@ def test_hp_split_represents_fp32_to_two_ulp_and_handles_extremes():
         assert torch.all((out.double() - (vals * mag).double()).abs() <= tol.double()), (mag, out, vals * mag)
     z = gemm_hp(hp_split(torch.zeros(4, 40).cuda()), hp_split(torch.ones(3, 40).cuda()))
     assert torch.all(z == 0)
+
+
+@pytest.mark.parametrize("xcd_skip", [0x00, 0x0F, 0xFE])
+def test_gemm_hp_grouped_queue_launch(xcd_skip):
+    """Three weight-gradient-shaped products (ragged M / N, deep K -> split-K slabs) in ONE queue-driven launch, on all XCDs, on
+    XCDs 4-7 only and on XCD 0 only: each result against fp64, run-to-run bitwise reproducible (which workgroup draws which unit
+    varies, the arithmetic of a unit does not), and the accumulate epilogue."""
+    from rnntransducer_amd.ops import gemm_hp_grouped, hp_split
+    g = torch.Generator().manual_seed(21)
+    Kc = 9000
+    shapes = [(700, 300), (512, 130), (260, 513)]
+    mats = [(torch.randn(Kc, m, generator=g) * torch.exp(torch.empty(Kc, 1).uniform_(-8, 0, generator=g)), torch.randn(Kc, n, generator=g))
+            for m, n in shapes]
+    pairs = [(hp_split(a.cuda(), transpose=True), hp_split(b.cuda(), transpose=True)) for a, b in mats]
+    outs = gemm_hp_grouped(pairs, xcd_skip=xcd_skip)
+    again = gemm_hp_grouped(pairs, xcd_skip=xcd_skip)
+    base = [torch.randn(m, n, generator=g) for m, n in shapes]
+    acc = gemm_hp_grouped(pairs, outs=[b.clone().cuda() for b in base], accumulate=True, xcd_skip=xcd_skip)
+    for (a, b), o, o2, o3, bs in zip(mats, outs, again, acc, base):
+        ref = a.double().T @ b.double()
+        scale = a.abs().double().T @ b.abs().double() + 1e-30
+        assert ((o.double().cpu() - ref).abs() / scale).max().item() < 2e-6
+        assert torch.equal(o, o2)
+        assert ((o3.double().cpu() - ref - bs.double()).abs() / (scale + bs.abs().double())).max().item() < 2e-6
+
+
+def test_gemm_hp_grouped_rejects_bad_arguments():
+    from rnntransducer_amd.ops import gemm_hp_grouped, hp_split
+    a, b = hp_split(torch.randn(64, 40).cuda(), transpose=True), hp_split(torch.randn(64, 24).cuda(), transpose=True)
+    with pytest.raises(ValueError):
+        gemm_hp_grouped([(a, b)] * 5)
+    with pytest.raises(ValueError):
+        gemm_hp_grouped([(a, b)], xcd_skip=0xFF)            # no XCD left
+    with pytest.raises(ValueError):
+        gemm_hp_grouped([(a, hp_split(torch.randn(65, 24).cuda(), transpose=True))])   # contraction lengths differ

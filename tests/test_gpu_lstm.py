@@ -275,3 +275,43 @@ def test_batches_beyond_one_launch_are_split_along_b():
         for name, p in ref.named_parameters():
             scale = max(p.grad.abs().max().item(), 1e-3)
             assert (getattr(hip, name).grad.double().cpu() - p.grad).abs().max().item() < GRAD_RTOL * scale + 1e-6, name
+
+
+@pytest.mark.parametrize("force_hp", [False, True])
+def test_backward_overlap_of_weight_gradients_equals_the_serial_backward(monkeypatch, force_hp):
+    """ops.LstmStackFn.backward issues rnnt_hip_lstm_bwd in two phases for stacks of >= 2 layers: recurrence + dx on the caller's
+    stream, weight / bias gradients on a second stream beside the next layer's recurrence (alternating workspaces).  Against the
+    single-call backward (RNNT_LSTM_NO_OVERLAP): bitwise equal while the products stay on gemm.hip; with the big products forced
+    onto the half-pair path the overlapped form uses the grouped queue launch (a different split-K partition): equal to 2e-6 of the
+    gradient's scale.  Three layers, dropout, ragged lengths, two backward passes through the same module (workspace reuse)."""
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    if force_hp:
+        monkeypatch.setenv("RNNT_GEMM_FORCE_HP", "1")
+    B, T, I, H, L = 32, 37, 136, 128, 3
+    torch.manual_seed(11)
+    hip = HipLSTM(I, H, L, dropout=0.25, bidirectional=True).cuda().train()
+    g = torch.Generator().manual_seed(4)
+    lens = torch.tensor([T] + torch.randint(1, T + 1, (B - 1,), generator=g).tolist(), dtype=torch.int32, device="cuda")
+    x = torch.randn(T, B, I, generator=g).cuda()
+    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
+    results = []
+    for serial in (False, True, False):
+        if serial:
+            monkeypatch.setenv("RNNT_LSTM_NO_OVERLAP", "1")
+        else:
+            monkeypatch.delenv("RNNT_LSTM_NO_OVERLAP", raising=False)
+        hip.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        torch.manual_seed(77)
+        hip._step = 5           # the dropout seed derives from (torch seed, module step counter): the same masks in all three runs
+        y = hip(xin, lens)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        results.append([xin.grad.clone()] + [p.grad.clone() for p in hip.parameters()])
+    over, ser, over2 = results
+    for a, b, c in zip(over, ser, over2):
+        assert torch.equal(a, c)                       # the overlapped form is reproducible run to run
+        if force_hp:
+            assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-3)
+        else:
+            assert torch.equal(a, b)
