@@ -1789,7 +1789,7 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
       else if (d->cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd3_kernel<N, 1>, k, p2, p2.lds_fwd, s, "lstm_fwd3"); \
       else rc = launch_persistent2(lstm_fwd3_kernel<N, 2>, k, p2, p2.lds_fwd, s, "lstm_fwd3");                     \
     } while (0)
-    if (((p2.MB == 4 && nks <= 4) || p2.MB == 5) && lstm5_supported(d->T, d->B, d->H, d->D, d->cell)) {  // v5: tagged-payload exchange, f16 matrix cores (lstm5.hip)
+    if (lstm5_supported(d->T, d->B, d->H, d->D, d->cell)) {  // v5: tagged-payload exchange, f16 matrix cores (lstm5.hip)
       rc = lstm5_fwd_launch(k, p2, d->cell, s);
     } else if (p2.MB == 5) {  // H = 640: 5 blocks, 8 waves x 3 k-steps over K padded to 768
       const size_t lds5 = p2.lds_fwd + 8 * 1 * 3 * 3 * 1024;  // one of the five blocks' pieces in LDS
@@ -1892,7 +1892,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       else if (d->cell == RNNT_CELL_GRU) LAUNCH_V4_B(N, 1);        \
       else LAUNCH_V4_B(N, 2);                                      \
     } while (0)
-    if (((p2.MB == 4 && nks <= 4) || p2.MB == 5) && lstm5_supported(d->T, d->B, d->H, d->D, d->cell)) {  // v5 (lstm5.hip)
+    if (lstm5_supported(d->T, d->B, d->H, d->D, d->cell)) {  // v5 (lstm5.hip)
       if (w.hp) {  // the recurrence also leaves the column maxima of dG (the scales of the half-pair dG^T planes): no extra pass
         const int64_t Mr = (int64_t)T * B, N4r = (int64_t)D * 4 * H;
         k.colmax = w.hp_amax + Mr + N4r + Mr;

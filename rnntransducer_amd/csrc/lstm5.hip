@@ -69,8 +69,8 @@ __device__ __forceinline__ bool poll_tagged(F&& load_and_check, unsigned* status
 // ================================================================================================
 // forward.  dynamic LDS: part[2 parities][NWV waves][MB blocks][64] f32x4 | wmax[8] | abort | pubs[16][HS]
 // NKS: 32-deep k-steps per wave (Kp = NWV * 32 * NKS >= H, zero padded).  CELL: 0 LSTM, 1 GRU, 2 tanh Elman RNN.
-// NWV x MB: 4 x 4 (H = 128..512: 16 units per workgroup) or 8 x 5 (H = 640: 20 units per workgroup so that a sync group has 32
-// members and fits one XCD; K padded to 768).  Wave w < MB owns gate-column block w (one cell per lane).
+// NWV x MB: 4 x 4 (H = 128..512: 16 units per workgroup), 8 x 5 (H = 640: 20 units per workgroup so that a sync group has 32
+// members and fits one XCD; K padded to 768) or 8 x 4 (H = 768 / 1024: NKS = 3 / 4, 48 / 64 workgroups per group).  Wave w < MB owns gate-column block w (one cell per lane).
 // ================================================================================================
 template <int NKS, int CELL, int NWV = 4, int MB = 4>
 __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
@@ -332,9 +332,10 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
 //   Arithmetic: dG rows scaled per (row, workgroup) by a power of two from the row's maximum over the 64 own columns (LDS
 //   ds_max), W_hh by the slice maximum; 3 f16 products; the product is descaled before it is published.
 // dynamic LDS: red[NT] f32x4 | dgs[16][DGS_LD] float | rowexp[2][16] | wmax[8] | abort
-// NMB: 16-unit output blocks per wave (Kp / 16 / NWV).  NWV x MB: 4 x 4 (H = 128..512) or 8 x 5 (H = 640, K padded to 768).
+// NMB: 16-unit output blocks per wave (Kp / 16 / NWV).  NWV x MB: 4 x 4 (H = 128..512), 8 x 5 (H = 640, K padded to 768) or 8 x 4
+// (H = 768 / 1024: 48 / 64 producers per group, NCMAX = 64; such a group spans XCDs and runs the write-through exchange).
 // ================================================================================================
-template <int NMB, int BQ, int CELL, int NWV = 4, int MB = 4>
+template <int NMB, int BQ, int CELL, int NWV = 4, int MB = 4, int NCMAX = 32>
 __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
   constexpr int HS = 4 * MB, UQ = MB, NT = 64 * NWV;
@@ -437,7 +438,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
 
   // gather: thread -> (row, unit quad) pair gpr and producer class gq; it sums the partial slices of producers gq, gq + NQ, ...
-  constexpr int NPAIR = NBR * UQ, NQ = NT / NPAIR, NLD = (32 + NQ - 1) / NQ;   // NC <= 32; threads beyond NQ * NPAIR only help elsewhere
+  constexpr int NPAIR = NBR * UQ, NQ = NT / NPAIR, NLD = (NCMAX + NQ - 1) / NQ;   // NC <= NCMAX; threads beyond NQ * NPAIR only help elsewhere
   const int gq = tid / NPAIR, gpr = tid % NPAIR;
   const bool gact = gq < NQ;
   const int grow = gpr / UQ, guq = gpr % UQ;
@@ -645,7 +646,11 @@ bool lstm5_supported(int T, int B, int H, int D, int cell) {
   if (getenv("RNNT_LSTM_NO_V5") || getenv("RNNT_LSTM_V1") || getenv("RNNT_LSTM_V2") || getenv("RNNT_LSTM_EXACT_MATH")) return false;
   if ((long)T * B * D * 4 * H * 4 >= (1l << 31)) return false;   // the stash is addressed with 32-bit buffer offsets
   const bool h640 = H == 640 && !getenv("RNNT_LSTM_NO_H640_FORM") && !getenv("RNNT_LSTM_NO_8WAVE");
-  return ((H % 128 == 0 && H >= 128 && H <= 512) || h640) && cell != RNNT_CELL_RNN_RELU;
+  // H = 768 / 1024 (8 waves, 48 / 64 workgroups per group): opt-in.  Such a group spans XCDs, every step moves 16 rows x H x 4 B to
+  // each of its workgroups through the fabric, and the shipped config (8 x 1024 bi-GRU, B = 16) measured 152.5 ms per step against
+  // 146.7 with lstm.hip's v3 / v4 forms (154.0 vs 145.6 with one 16-row group per direction instead of two 8-row groups).
+  const bool wide = (H == 768 || H == 1024) && getenv("RNNT_LSTM_V5_WIDE") && !getenv("RNNT_LSTM_NO_8WAVE");
+  return ((H % 128 == 0 && H >= 128 && H <= 512) || h640 || wide) && cell != RNNT_CELL_RNN_RELU;
 }
 
 int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
@@ -656,6 +661,20 @@ int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
     if (cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd5_kernel<3, 0, 8, 5>, k, pl, lds, s, "lstm_fwd5", 512);
     else if (cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd5_kernel<3, 1, 8, 5>, k, pl, lds, s, "lstm_fwd5", 512);
     else rc = launch_persistent2(lstm_fwd5_kernel<3, 2, 8, 5>, k, pl, lds, s, "lstm_fwd5", 512);
+    return rc;
+  }
+  if (k.H > 512) {   // H = 768 / 1024: 8 waves x 3 / 4 k-steps each
+    const size_t lds = (size_t)2 * 8 * 4 * 64 * 16 + 32 + 16 + 16 * 16 * 4;
+#define L58(N)                                                                                                       \
+    do {                                                                                                             \
+      if (cell == RNNT_CELL_LSTM) rc = launch_persistent2(lstm_fwd5_kernel<N, 0, 8, 4>, k, pl, lds, s, "lstm_fwd5", 512);      \
+      else if (cell == RNNT_CELL_GRU) rc = launch_persistent2(lstm_fwd5_kernel<N, 1, 8, 4>, k, pl, lds, s, "lstm_fwd5", 512);  \
+      else rc = launch_persistent2(lstm_fwd5_kernel<N, 2, 8, 4>, k, pl, lds, s, "lstm_fwd5", 512);                   \
+    } while (0)
+    if (k.Kp == 768) L58(3);
+    else if (k.Kp == 1024) L58(4);
+    else set_error("lstm_fwd5: H = %d not supported", k.H);
+#undef L58
     return rc;
   }
   const size_t lds = (size_t)2 * 4 * 4 * 64 * 16 + 32 + 16 + 16 * 16 * 4;
@@ -689,6 +708,21 @@ int lstm5_bwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
     if (cell == RNNT_CELL_LSTM) B5Q(6, 0, 8, 5);
     else if (cell == RNNT_CELL_GRU) B5Q(6, 1, 8, 5);
     else B5Q(6, 2, 8, 5);
+    return rc;
+  }
+  if (k.H > 512) {   // H = 768 / 1024: 8 waves, 6 / 8 output blocks each, up to 64 producers per group
+    const int threads = 512;
+    const size_t lds = (size_t)512 * 16 + 16 * (32 * 2 + 4) * 4 + 32 * 4 + 32 + 16;
+#define B58(NM)                                          \
+    do {                                                 \
+      if (cell == RNNT_CELL_LSTM) B5Q(NM, 0, 8, 4, 64);  \
+      else if (cell == RNNT_CELL_GRU) B5Q(NM, 1, 8, 4, 64); \
+      else B5Q(NM, 2, 8, 4, 64);                         \
+    } while (0)
+    if (k.Kp == 768) B58(6);
+    else if (k.Kp == 1024) B58(8);
+    else set_error("lstm_bwd5: H = %d not supported", k.H);
+#undef B58
     return rc;
   }
   const int threads = 256;

@@ -315,3 +315,14 @@ def test_backward_overlap_of_weight_gradients_equals_the_serial_backward(monkeyp
             assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-3)
         else:
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cell,B,T,I,H,bi", [("lstm", 16, 6, 24, 1024, True), ("gru", 9, 5, 16, 768, True), ("lstm", 5, 4, 8, 1024, False)])
+def test_v5_recurrences_at_768_and_1024_are_opt_in_and_correct(monkeypatch, cell, B, T, I, H, bi):
+    """RNNT_LSTM_V5_WIDE=1 runs the tagged-payload / half-pair recurrences at H = 768 / 1024 (8 waves, 48 / 64 producers per sync
+    group).  Not the default — measured slower than the v3 / v4 forms at the shipped config's size (lstm5.hip) — but kept correct."""
+    monkeypatch.setenv("RNNT_LSTM_V5_WIDE", "1")
+    if cell == "lstm":
+        test_lstm_stack_fwd_bwd(B, T, I, H, 1, bi)
+    else:
+        test_gru_and_elman_cells_fwd_bwd(cell, B, T, I, H, 1, bi)
