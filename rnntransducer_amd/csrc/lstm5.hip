@@ -54,7 +54,7 @@ __device__ __forceinline__ bool poll_tagged(F&& load_and_check, unsigned* status
   const unsigned long long t0 = wall_clock64();
   unsigned spins = 0;
   while (true) {
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(1);   // (no sleep, or 2 / 4 / 8 times longer: within +-0.5 % of this per c2 step — the loop's pace is not the limit)
     if (__all(load_and_check())) return true;
     if ((++spins & 63u) == 0u) {
       const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -663,7 +663,11 @@ int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
     else rc = launch_persistent2(lstm_fwd5_kernel<3, 2, 8, 5>, k, pl, lds, s, "lstm_fwd5", 512);
     return rc;
   }
-  if (k.H > 512) {   // H = 768 / 1024: 8 waves x 3 / 4 k-steps each
+  // H = 512: 8 waves x 2 k-steps instead of 4 x 4.  The MFMA phase is pipe-bound either way (192 MFMAs per workgroup and step on 4
+  // SIMDs = 768 cycles) but 8 waves spread the operand polls, the de-interleave and the stash over twice the issue slots:
+  // 4 900 vs 5 324 cycles per step, 31.4 vs 32.1 ms per c2 step (profiles/r02_lstm_phase_cycles_v5.txt).  RNNT_LSTM_FWD5_4W=1: 4 waves.
+  const bool w8 = k.H == 512 && !getenv("RNNT_LSTM_FWD5_4W") && !getenv("RNNT_LSTM_NO_8WAVE");
+  if (k.H > 512 || w8) {   // H = 768 / 1024: 8 waves x 3 / 4 k-steps each
     const size_t lds = (size_t)2 * 8 * 4 * 64 * 16 + 32 + 16 + 16 * 16 * 4;
 #define L58(N)                                                                                                       \
     do {                                                                                                             \
@@ -673,6 +677,7 @@ int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
     } while (0)
     if (k.Kp == 768) L58(3);
     else if (k.Kp == 1024) L58(4);
+    else if (k.Kp == 512) L58(2);
     else set_error("lstm_fwd5: H = %d not supported", k.H);
 #undef L58
     return rc;
@@ -710,6 +715,8 @@ int lstm5_bwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
     else B5Q(6, 2, 8, 5);
     return rc;
   }
+  // (H = 512 with 8 waves x 4 output blocks: the MFMA + publication phase drops from 1 961 to 1 432 cycles but the wait for the
+  //  partial sums grows from 768 to 1 894: 5 953 vs 5 156 cycles per step -> stays at 4 waves)
   if (k.H > 512) {   // H = 768 / 1024: 8 waves, 6 / 8 output blocks each, up to 64 producers per group
     const int threads = 512;
     const size_t lds = (size_t)512 * 16 + 16 * (32 * 2 + 4) * 4 + 32 * 4 + 32 + 16;

@@ -149,6 +149,14 @@ def test_lstm_v1_fallback_kernels_still_match(monkeypatch, B, T, I, H, L, bi):
     test_lstm_stack_fwd_bwd(B, T, I, H, L, bi)
 
 
+@pytest.mark.parametrize("env", ["RNNT_LSTM_FWD5_4W", "RNNT_LSTM_NO_V5"])
+def test_lstm_h512_alternative_forward_forms_still_match(monkeypatch, env):
+    """H = 512 runs the v5 forward with 8 waves x 2 k-steps by default; the 4-wave x 4 k-step form (RNNT_LSTM_FWD5_4W) and round 1's
+    flag-protocol / bf16-piece kernels (RNNT_LSTM_NO_V5) stay selectable and correct."""
+    monkeypatch.setenv(env, "1")
+    test_lstm_stack_fwd_bwd(32, 17, 80, 512, 2, True)
+
+
 @pytest.mark.parametrize("B,T,I,H,L,bi", [(32, 11, 16, 512, 1, True), (3, 12, 40, 640, 1, True), (64, 9, 16, 512, 1, True)])
 def test_lstm_v2_lds_resident_kernels_still_match(monkeypatch, B, T, I, H, L, bi):
     """The v2 kernels (W_hh slice in LDS, f32-input 4x4x1 MFMA, gathered dG) remain the path for every H outside
