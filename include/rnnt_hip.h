@@ -197,6 +197,9 @@ typedef struct rnnt_lstm_desc {
 size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D);
 /* largest B one call accepts for (H, D, cell); 0 = shape unsupported.  Bigger batches: split along B (rows are independent). */
 int32_t rnnt_hip_lstm_max_batch(int32_t H, int32_t D, int32_t cell);
+/* XCDs (of 8) a recurrence of this shape leaves without a workgroup (0 when its groups fill the chip or are not placed per XCD):
+ * what a caller looks at before it puts phase 2 of one layer beside phase 1 of the next (rnnt_lstm_bwd_desc.phase). */
+int32_t rnnt_hip_lstm_free_xcds(int32_t T, int32_t B, int32_t H, int32_t D, int32_t cell);
 int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream);
 
 typedef struct rnnt_lstm_bwd_desc {

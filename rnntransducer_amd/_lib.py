@@ -85,6 +85,7 @@ SYMBOLS = {
     "rnnt_hip_gemm_hp_grouped": (C.c_int, [C.POINTER(HpProblem), c_i32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_lstm_workspace_bytes": (C.c_size_t, [c_i32] * 5),
     "rnnt_hip_lstm_max_batch": (c_i32, [c_i32, c_i32, c_i32]),
+    "rnnt_hip_lstm_free_xcds": (c_i32, [c_i32] * 5),
     "rnnt_hip_lstm_fwd": (C.c_int, [C.POINTER(LstmDesc), C.c_void_p]),
     "rnnt_hip_lstm_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), C.c_void_p]),
     "rnnt_hip_lstm_check": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1711,6 +1711,21 @@ extern "C" int32_t rnnt_hip_lstm_max_batch(int32_t H, int32_t D, int32_t cell) {
   return best;
 }
 
+// the placement rule shared by the backward (which XCDs its grouped products avoid) and the caller's decision to overlap at all
+static int recurrence_xcds(int T, int B, int H, int D, int cell, int cus) {
+  Plan2 p2;
+  if (!make_plan3(B, H, D, cus, true, &p2) || !lstm5_supported(T, B, H, D, cell)) return 8;
+  const int NG = D * p2.G;
+  return (NG <= 4 && p2.NC <= 32 && !getenv("RNNT_LSTM_NO_XCD_STRIDE")) ? NG : 8;   // launch_persistent2: stride 8, group g on XCD g
+}
+
+extern "C" int32_t rnnt_hip_lstm_free_xcds(int32_t T, int32_t B, int32_t H, int32_t D, int32_t cell) {
+  int cus = device_cus();
+  if (cus <= 0) cus = 256;
+  if (T < 1 || B < 1 || H < 4 || D < 1 || D > 2) return 0;
+  return 8 - recurrence_xcds(T, B, H, D, cell, cus);
+}
+
 extern "C" size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D) {
   Plan pl;
   int cus = device_cus();
@@ -1908,7 +1923,10 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       if (do_recur) rc = lstm5_bwd_launch(k, p2, d->cell, s);
       // the weight-gradient products of THIS layer may run beside the recurrence of the next one (same shape): that one sits on
       // XCDs 0 .. D*G-1 (launch_persistent2's stride-8 placement), the products keep to the others
-      if (bd->beside_recurrence && D * p2.G <= 4 && p2.NC <= 64) xcd_skip = (1u << (D * p2.G)) - 1u;
+      if (bd->beside_recurrence) {
+        const int used = recurrence_xcds(T, B, H, D, d->cell, cus);
+        if (used <= 4) xcd_skip = (1u << used) - 1u;
+      }
     } else if (!do_recur) {
       // phase 2: nothing to launch here
     } else if (p2.MB == 5) {  // H = 640: own 80 gate columns (3 k-steps), 48 output blocks over 8 waves

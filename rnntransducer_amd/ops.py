@@ -399,7 +399,11 @@ class LstmStackFn(torch.autograd.Function):
         # Only dx is on the chain to the layer below: the weight / bias gradients of layer l (phase 2 of rnnt_hip_lstm_bwd) go to a
         # second stream and run beside the reverse-time recurrence of layer l-1 (phase 1), which leaves most of the chip idle.
         # Two workspaces alternate by layer parity so that phase 1 of layer l-1 never touches what phase 2 of layer l still reads.
-        overlap = L >= 2 and not os.environ.get("RNNT_LSTM_NO_OVERLAP")
+        # Worth it only where the recurrence leaves XCDs free (c3: 4 of 8, +3.9 %): when its groups fill the chip (c2: 8 groups x 32
+        # workgroups) the second stream's kernels merely queue behind it (+0.1..0.7 %, and every per-kernel timing turns into a
+        # shared-device duration).  RNNT_LSTM_OVERLAP=1 forces it (tests), RNNT_LSTM_NO_OVERLAP=1 forbids it.
+        overlap = L >= 2 and not os.environ.get("RNNT_LSTM_NO_OVERLAP") and (
+            bool(os.environ.get("RNNT_LSTM_OVERLAP")) or _lib.lib().rnnt_hip_lstm_free_xcds(T, B, H, D, cell) >= 4)
         main = torch.cuda.current_stream()
         side = _side_stream(dy.device) if overlap else None
         wss = [ctx.ws, torch.empty_like(ctx.ws)] if overlap else [ctx.ws, ctx.ws]

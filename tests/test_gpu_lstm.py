@@ -308,6 +308,7 @@ def test_backward_overlap_of_weight_gradients_equals_the_serial_backward(monkeyp
             monkeypatch.setenv("RNNT_LSTM_NO_OVERLAP", "1")
         else:
             monkeypatch.delenv("RNNT_LSTM_NO_OVERLAP", raising=False)
+            monkeypatch.setenv("RNNT_LSTM_OVERLAP", "1")   # this shape's recurrence fills the chip: not overlapped by default
         hip.zero_grad()
         xin = x.clone().requires_grad_(True)
         torch.manual_seed(77)
@@ -334,3 +335,34 @@ def test_v5_recurrences_at_768_and_1024_are_opt_in_and_correct(monkeypatch, cell
         test_lstm_stack_fwd_bwd(B, T, I, H, 1, bi)
     else:
         test_gru_and_elman_cells_fwd_bwd(cell, B, T, I, H, 1, bi)
+
+
+def test_backward_overlap_is_chosen_where_the_recurrence_leaves_xcds_free():
+    """B = 8, H = 512, two directions (the c3 shape): 4 sync groups on 4 XCDs -> phase 2 of a layer runs beside phase 1 of the next
+    on the other 4 (grouped queue launch that skips XCDs 0-3).  B = 32 (c2): 8 groups fill the chip -> single-call backward."""
+    from rnntransducer_amd import _lib
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    assert _lib.lib().rnnt_hip_lstm_free_xcds(100, 8, 512, 2, 0) == 4
+    assert _lib.lib().rnnt_hip_lstm_free_xcds(100, 32, 512, 2, 0) == 0
+    assert _lib.lib().rnnt_hip_lstm_free_xcds(100, 16, 1024, 2, 1) == 0
+    B, T, I, H, L = 8, 140, 1024, 512, 2      # T*B >= 1024 and 4H*D*T*B >= 2^22: the half-pair path by itself
+    torch.manual_seed(5)
+    ref = nn.LSTM(I, H, L, batch_first=True, bidirectional=True).double()
+    hip = HipLSTM(I, H, L, dropout=0.0, bidirectional=True)
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hip = hip.cuda()
+    g = torch.Generator().manual_seed(2)
+    lens = [T] + torch.randint(T // 2, T + 1, (B - 1,), generator=g).tolist()
+    x = torch.randn(B, T, I, generator=g)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    dy = torch.randn(B, T, 2 * H, generator=g)
+    ref_out, ref_dx = _oracle(x, lens, ref, dy)
+    x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
+    y = hip(x_tm, torch.tensor(lens, dtype=torch.int32, device="cuda"))
+    y.backward(dy.transpose(0, 1).contiguous().cuda())
+    assert (y.detach().transpose(0, 1).double().cpu() - ref_out).abs().max().item() < FWD_ATOL
+    for name, p in ref.named_parameters():
+        scale = max(p.grad.abs().max().item(), 1e-3)
+        assert (getattr(hip, name).grad.double().cpu() - p.grad).abs().max().item() < GRAD_RTOL * scale + 1e-6, name
+    assert (x_tm.grad.transpose(0, 1).double().cpu() - ref_dx).abs().max().item() < GRAD_RTOL * max(ref_dx.abs().max().item(), 1e-3) + 1e-6
