@@ -124,6 +124,11 @@ int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream);
 size_t rnnt_hip_hp_bytes(int64_t rows, int64_t K);
 int rnnt_hip_hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, int32_t transpose, int64_t src_rows, int64_t shift,
                       void* planes, uint32_t* amax, int32_t amax_given, void* stream);
+/* both orientations of x (M x C, row stride ld) in one pass: planes_rm = what transpose == 0 writes given the row maxima rowmax[M],
+ * planes_t = what transpose == 1 (shift 0, contraction length M) writes given the column maxima colmax[C]; both tables are inputs
+ * (rnnt_hip_lstm_bwd's recurrence leaves them for dG).  Bitwise the same planes as two rnnt_hip_hp_split calls. */
+int rnnt_hip_hp_split_both(const float* x, int64_t M, int64_t C, int64_t ld, const uint32_t* rowmax, const uint32_t* colmax,
+                           void* planes_rm, void* planes_t, void* stream);
 size_t rnnt_hip_gemm_hp_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int rnnt_hip_gemm_hp(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N, int64_t K,
                      float* C, int64_t ldc, const float* bias, uint32_t flags, void* workspace, size_t workspace_bytes,
@@ -192,6 +197,9 @@ typedef struct rnnt_lstm_desc {
                      * Read it back with an asynchronous 4-byte copy whenever convenient (rnntransducer_amd does so once per
                      * optimizer step, no extra synchronisation).  NULL: word 0 of the workspace, reset per launch, read by
                      * rnnt_hip_lstm_check(). */
+  float x_abs_bound; /* optional (backward): > 0 = the caller guarantees |x| <= x_abs_bound everywhere (x is the dropped output of
+                     * a bounded cell below: 1 / (1 - p)).  The half-pair planes of x^T then take this as their scale instead of
+                     * a pass over x for its column maxima (absolute error of an element <= 2^-39 x_abs_bound either way).  0: measure. */
 } rnnt_lstm_desc;
 
 size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D);

@@ -34,7 +34,7 @@ class LstmDesc(C.Structure):
                 ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2), ("y", C.c_void_p),
                 ("y_drop", C.c_void_p), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
                 ("gates", C.c_void_p), ("cst", C.c_void_p), ("aux", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t), ("status", C.c_void_p)]
+                ("workspace_bytes", C.c_size_t), ("status", C.c_void_p), ("x_abs_bound", C.c_float)]
 
 
 class LstmBwdDesc(C.Structure):
@@ -81,6 +81,7 @@ SYMBOLS = {
     "rnnt_hip_gemm_hp_workspace_bytes": (C.c_size_t, [c_i64, c_i64, c_i64]),
     "rnnt_hip_gemm_hp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, c_i64, C.c_void_p,
                                   C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnnt_hip_hp_split_both": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rnnt_hip_gemm_hp_grouped_workspace_bytes": (C.c_size_t, [C.POINTER(HpProblem), c_i32]),
     "rnnt_hip_gemm_hp_grouped": (C.c_int, [C.POINTER(HpProblem), c_i32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnnt_hip_lstm_workspace_bytes": (C.c_size_t, [c_i32] * 5),

@@ -49,6 +49,9 @@ int hp_colmax(const float* x, int64_t rows, int64_t C, int64_t ld, uint32_t* ama
 int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, void* planes, hipStream_t s);  // writes amax[rows]
 int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, int64_t shift, const uint32_t* amax, void* planes,
                hipStream_t s);
+// both orientations in one pass; rowmax[M] and colmax[C] given
+int hp_split_both(const float* x, int64_t M, int64_t C, int64_t ld, const uint32_t* rowmax, const uint32_t* colmax, void* planes_rm,
+                  void* planes_t, hipStream_t s);
 size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N, int64_t K, float* C,
             int64_t c_div, int64_t c_so, int64_t c_si, const float* bias, unsigned flags, void* workspace, size_t workspace_bytes,

@@ -170,6 +170,61 @@ __global__ void __launch_bounds__(256) hp_split_t_kernel(const float* __restrict
   }
 }
 
+// Both orientations of one matrix in ONE pass over it (dG of an LSTM layer: row-major planes for dX = dG . W_ih, transposed planes for
+// dW = dG^T . X): x (M x C, row stride ld) -> out_rm[M][Cp/32] lines scaled by rowmax[r]  and  out_t[C][Mp/32] lines scaled by
+// colmax[c]; both tables are GIVEN (the backward recurrence leaves them).  Workgroup = 32 rows x 256 columns: every thread loads 8
+// consecutive values of a row, emits their row-major half-line from registers and parks them in LDS for the transposed store.
+__global__ void __launch_bounds__(256) hp_split_both_kernel(const float* __restrict__ x, int M, int C, long ld, const unsigned* __restrict__ rowmax,
+                                                            const unsigned* __restrict__ colmax, char* __restrict__ out_rm, char* __restrict__ out_t) {
+  __shared__ float tile[32][257];
+  const int kb = blockIdx.x, c0 = blockIdx.y * 256;
+  const int tid = threadIdx.x;
+  const int Cp = (C + 31) & ~31;
+  const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 8 * q + (tid >> 5), col = 8 * (tid & 31);
+    const int r = kb * 32 + row, c = c0 + col;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < M && c < C) {
+      const float* src = x + (long)r * ld + c;
+      if (vec && c + 7 < C) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c + e < C) v[e] = src[e];
+      }
+    }
+    if (r < M && c < Cp) {
+      u32x4 hi, lo;
+      hp_split8(v, hp_scale_from_amax(rowmax[r]), hi, lo);
+      char* dst = out_rm + ((long)r * (Cp >> 5) + (c >> 5)) * 128 + 16 * ((c >> 3) & 3);
+      *reinterpret_cast<u32x4*>(dst) = hi;
+      *reinterpret_cast<u32x4*>(dst + 64) = lo;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[row][col + e] = v[e];
+  }
+  __syncthreads();
+  const int Mp32 = (M + 31) >> 5;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int rl = (tid >> 2) + 64 * ps, ch = tid & 3;
+    if (c0 + rl < C) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[8 * ch + e][rl];
+      u32x4 hi, lo;
+      hp_split8(v, hp_scale_from_amax(colmax[c0 + rl]), hi, lo);
+      char* dst = out_t + ((long)(c0 + rl) * Mp32 + kb) * 128 + 16 * ch;
+      *reinterpret_cast<u32x4*>(dst) = hi;
+      *reinterpret_cast<u32x4*>(dst + 64) = lo;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 struct HpGemmK {
   int M, N, nkt;             // nkt = K-tiles (32 k each) of the whole contraction
@@ -549,6 +604,16 @@ int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, i
   return RNNT_OK;
 }
 
+int hp_split_both(const float* x, int64_t M, int64_t C, int64_t ld, const uint32_t* rowmax, const uint32_t* colmax, void* planes_rm,
+                  void* planes_t, hipStream_t s) {
+  if (M == 0 || C == 0) return RNNT_OK;
+  ProfScope prof(RNNT_K_HP_SPLIT, 12.0 * (double)M * (double)C, s);
+  hipLaunchKernelGGL(hp_split_both_kernel, dim3((unsigned)ceil_div(M, 32), (unsigned)ceil_div(C, 256)), dim3(256), 0, s, x, (int)M, (int)C, (long)ld,
+                     rowmax, colmax, (char*)planes_rm, (char*)planes_t);
+  RNNT_CHECK_LAUNCH();
+  return RNNT_OK;
+}
+
 size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   const long tiles = ceil_div(M, HP_BM) * ceil_div(N, HP_BN);   // the coarser tiling: an upper bound on the splits either kernel takes
   const long nkt = ceil_div(K, HP_BK);
@@ -739,4 +804,12 @@ extern "C" int rnnt_hip_gemm_hp_grouped(const rnnt_hp_problem* problems, int32_t
   }
   return hp_gemm_grouped(pr, n, xcd_skip, reinterpret_cast<unsigned*>(workspace), (char*)workspace + 256, workspace_bytes - 256,
                          (hipStream_t)stream);
+}
+
+extern "C" int rnnt_hip_hp_split_both(const float* x, int64_t M, int64_t C, int64_t ld, const uint32_t* rowmax, const uint32_t* colmax,
+                                      void* planes_rm, void* planes_t, void* stream) {
+  RNNT_CHECK_ARG(x && rowmax && colmax && planes_rm && planes_t && M >= 0 && C >= 0 && ld >= C, "hp_split_both: bad arguments");
+  RNNT_CHECK_ARG(M < (1ll << 31) && C < (1ll << 31), "hp_split_both: dims must fit 31 bits");
+  RNNT_CHECK_ARG(((reinterpret_cast<uintptr_t>(planes_rm) | reinterpret_cast<uintptr_t>(planes_t)) & 127) == 0, "hp_split_both: planes must be 128-byte aligned");
+  return hp_split_both(x, M, C, ld, rowmax, colmax, planes_rm, planes_t, (hipStream_t)stream);
 }

@@ -27,6 +27,8 @@
 // with sc1 loads.  No dispatch-order or XCD-placement assumption; all spins are bounded (status word).
 #include "lstm_shared.hpp"
 
+#include <string.h>
+
 namespace rnnt {
 namespace {
 
@@ -1656,6 +1658,7 @@ int check_desc(const rnnt_lstm_desc* d, Plan* pl, LstmWs* w) {
     RNNT_CHECK_ARG(d->w_ih[k] && d->w_hh[k] && d->b_ih[k] && d->b_hh[k], "lstm: null weight (direction %d)", k);
   RNNT_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "lstm: dropout_p must be in [0,1)");
   RNNT_CHECK_ARG(d->dropout_p == 0.f || d->y_drop, "lstm: dropout_p > 0 needs y_drop");
+  RNNT_CHECK_ARG(d->x_abs_bound >= 0.f && d->x_abs_bound < 1e30f, "lstm: x_abs_bound must be 0 (measure) or a finite positive bound");
   *w = carve_lstm(d->workspace, d->T, d->B, d->I, d->H, d->D, *pl);
   RNNT_CHECK_ARG(d->workspace && d->workspace_bytes >= w->total, "lstm: workspace too small (%zu < %zu)",
                  d->workspace_bytes, w->total);
@@ -1689,6 +1692,7 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
   k->hw_math = getenv("RNNT_LSTM_EXACT_MATH") ? 0 : 1;
   k->colmax = k->colmax_h = nullptr;
+  k->rowmax = nullptr;
 }
 
 }  // namespace
@@ -1787,8 +1791,8 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
     if (int rc = rnnt_hip_gemm_f32(&g, s)) return rc;
   }
   // 3. the recurrence
-  RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, w.sync_bytes, s));
-  RNNT_CHECK_HIP(hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+  // sync block and exchange buffers are neighbours in the workspace (carve_lstm): one fill
+  RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, (size_t)(reinterpret_cast<char*>(w.hx) - reinterpret_cast<char*>(w.flags)) + w.hx_bytes, s));
   LstmK k;
   fill_kernel_args(d, pl, w, &k);
   int rc = RNNT_OK;
@@ -1875,10 +1879,8 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   const bool do_recur = bd->phase != RNNT_LSTM_BWD_WEIGHTS, do_weights = bd->phase != RNNT_LSTM_BWD_RECUR;
 
   // 1. reverse-time recurrence: gates (activated) -> dG in place
-  if (do_recur) {
-    RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, w.sync_bytes, s));
-    RNNT_CHECK_HIP(hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
-  }
+  if (do_recur)   // sync block and exchange buffers are neighbours in the workspace (carve_lstm): one fill
+    RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, (size_t)(reinterpret_cast<char*>(w.hx) - reinterpret_cast<char*>(w.flags)) + w.hx_bytes, s));
   LstmK k;
   fill_kernel_args(d, pl, w, &k);
   k.dy = bd->dy;
@@ -1888,7 +1890,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   auto adopt = [&](const Plan2& q) {
     k.NC = q.NC; k.Hs = q.HS; k.G = q.G; k.Bg = q.Bg; k.Kp = q.Kp;
   };
-  bool fused_db = false, colmax_done = false;
+  bool fused_db = false, colmax_done = false, rowmax_done = false;
   int db_rows = 0;
   unsigned xcd_skip = 0;
   if (make_plan3(d->B, d->H, d->D, cus, true, &p2)) {
@@ -1914,10 +1916,16 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
         const int64_t Mr = (int64_t)T * B, N4r = (int64_t)D * 4 * H;
         k.colmax = w.hp_amax + Mr + N4r + Mr;
         k.colmax_h = w.hp_amax + 2 * Mr + 2 * N4r + 2 * I + (int64_t)D * H;
-        if (do_recur) {
-          RNNT_CHECK_HIP(hipMemsetAsync(k.colmax, 0, (size_t)N4r * 4, s));
-          RNNT_CHECK_HIP(hipMemsetAsync(k.colmax_h, 0, (size_t)N4r * 4, s));
+        // LSTM / Elman layers that hand on dx: the recurrence also leaves the row maxima, and ONE pass over dG then writes both
+        // orientations of its planes (hp_split_both) instead of a row-major pass that measures each row first plus a transposed pass
+        unsigned* fill_from = k.colmax;
+        if (!gru && I >= 128 && bd->dx && !getenv("RNNT_GEMM_HP_NO_FUSED_SPLIT")) {
+          k.rowmax = w.hp_amax + Mr + N4r;   // = a_dgr below, directly in front of the column table
+          fill_from = k.rowmax;
+          rowmax_done = true;
         }
+        if (do_recur)   // one fill from the first table to the end of the last (the tables in between are written later)
+          RNNT_CHECK_HIP(hipMemsetAsync(fill_from, 0, (size_t)(k.colmax_h + N4r - fill_from) * 4, s));
         colmax_done = true;
       }
       if (do_recur) rc = lstm5_bwd_launch(k, p2, d->cell, s);
@@ -1990,11 +1998,15 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   uint32_t* a_x = w.hp ? a_w + I : nullptr;
   uint32_t* a_y = w.hp ? a_x + I : nullptr;
   if (w.hp) {  // half-pair planes of dG in both orientations (gemm_hp.hip is NT-only: transposed operands are materialised)
-    if (do_recur && hp_in && bd->dx)
-      if ((rc = hp_split(d->gates, M, N4, N4, a_dgr, w.hp_dg, s))) return rc;
+    const bool both = rowmax_done && colmax_done && hp_in && bd->dx;   // (same in both phases of a two-phase backward)
+    if (do_recur && hp_in && bd->dx) {
+      if (both) rc = hp_split_both(d->gates, M, N4, N4, a_dgr, a_dgc, w.hp_dg, w.hp_dgt, s);
+      else rc = hp_split(d->gates, M, N4, N4, a_dgr, w.hp_dg, s);
+      if (rc) return rc;
+    }
     if (do_weights && !colmax_done)
       if ((rc = hp_colmax(d->gates, M, N4, N4, a_dgc, s))) return rc;
-    if (do_weights)
+    if (do_weights && !both)
       if ((rc = hp_split_t(d->gates, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
   }
   // 2. dX = dG . W_ih'   (needs the permuted weights: rebuild them, the forward copy may have been overwritten)
@@ -2025,7 +2037,11 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   // 3. dW_ih' = dG^T . X  (both directions at once), un-permute rows into torch layout
   {
     if (hp_in) {
-      if ((rc = hp_colmax(d->x, M, I, I, a_x, s))) return rc;
+      if (d->x_abs_bound > 0.f) {   // bounded input (the dropped output of the layer below): its bound is the scale, no pass over x
+        uint32_t bits;
+        memcpy(&bits, &d->x_abs_bound, 4);
+        RNNT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)a_x, (int)bits, (size_t)I, s));
+      } else if ((rc = hp_colmax(d->x, M, I, I, a_x, s))) return rc;
       if ((rc = hp_split_t(d->x, I, M, I, M, 0, a_x, w.hp_x, s))) return rc;     // X^T: (I, contraction T*B)
       if (!grouped)
         if ((rc = hp_gemm(w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, M, w.wp, 1, I, 0, nullptr, 0, w.scratch, w.scratch_bytes, s))) return rc;
@@ -2047,7 +2063,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   }
   // 4. dW_hh'[d] = sum_t dG[t]^T . h_prev(t): time-shifted views of dG and y (padded frames are zero in both)
   if (w.hp && T > 1) {
-    if ((rc = hp_colmax(d->y, M, (int64_t)D * H, (int64_t)D * H, a_y, s))) return rc;
+    if (d->cell != RNNT_CELL_RNN_RELU) {   // |h| < 1 for LSTM / GRU / tanh cells: the planes of h^T take 1.0 as their scale
+      RNNT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)a_y, 0x3f800000, (size_t)D * H, s));
+    } else if ((rc = hp_colmax(d->y, M, (int64_t)D * H, (int64_t)D * H, a_y, s))) return rc;
     if (gru) {  // hidden-side gate gradients differ from the input-side ones in the n gate: their own transposed planes
       if (colmax_done) a_dgc = a_y + (int64_t)D * H;   // left there by the v5 recurrence
       else if ((rc = hp_colmax(ghid, M, N4, N4, a_dgc, s))) return rc;

@@ -602,6 +602,12 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
     const float dy_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, s + 1 < T ? y_off + y_step : OOB, 0, 0));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dg4), g_rsrc, g_off, 0, 0);
     if constexpr (CELL == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dgh4), a_rsrc, g_off, 0, 0);
+    if constexpr (CELL != 1) {   // (GRU: input- and hidden-side gradients differ; its caller measures the rows itself)
+      if (p.rowmax && tid < NBR) {   // this workgroup's share of the frame rows' maxima (rowexp of this parity is cleared a step later)
+        const unsigned m = rowexp[(s & 1) * 16 + tid];
+        if (m != 0u && tid < p.Bg && b0 + tid < B) atomicMax(p.rowmax + (long)t * B + b0 + tid, m);
+      }
+    }
     g_off += g_step;
     c_off += c_step;
     y_off += y_step;

@@ -36,6 +36,8 @@ struct LstmK {
   int NGL;         // v2+: launch stride of the group index (>= D*G): gid = blockIdx % NGL, blocks with gid >= D*G exit at once
   unsigned* colmax;    // v5 backward (or nullptr): per gate column (D*4H) running maximum of |dG| over all frames and rows (fp32 bit
   unsigned* colmax_h;  // patterns, zeroed by the host), input side / hidden side (GRU) — the column scales of the half-pair dG^T planes
+  unsigned* rowmax;    // v5 backward, LSTM / Elman (or nullptr): per frame row (T*B) maximum of |dG| over all gate columns of both
+                       // directions (zeroed by the host) — the row scales of the half-pair dG planes
   int hw_math;     // v2: v_exp_f32 / v_rcp_f32 cell math (default; measured whole-model loss delta identical to the ocml expf +
                    // IEEE-division form, which RNNT_LSTM_EXACT_MATH=1 selects)
 };

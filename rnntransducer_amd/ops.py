@@ -418,6 +418,8 @@ class LstmStackFn(torch.autograd.Function):
             aux = torch.empty_like(gates) if cell == 1 else None
             _fill_lstm_desc(bd.f, T, B, I, H, D, ctx.lens, x_l, wl, y_l, y_l if p > 0 else None, p, seed + layer, gates,
                             cst, wss[layer % 2], cell, aux)
+            if layer > 0 and cell != 3:   # x of this layer is the (dropped) output of a bounded cell: |x| <= 1 / (1 - p) of the layer below
+                bd.f.x_abs_bound = 1.0 / (1.0 - ctx.saved[layer - 1][4])
             bd.dy = _addr(dy)
             need_dx = layer > 0 or ctx.x_needs_grad
             dx = torch.empty(T, B, I, device=dy.device, dtype=torch.float32) if need_dx else None

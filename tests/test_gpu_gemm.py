@@ -289,3 +289,23 @@ def test_gemm_hp_grouped_rejects_bad_arguments():
         gemm_hp_grouped([(a, b)], xcd_skip=0xFF)            # no XCD left
     with pytest.raises(ValueError):
         gemm_hp_grouped([(a, hp_split(torch.randn(65, 24).cuda(), transpose=True))])   # contraction lengths differ
+
+
+@pytest.mark.parametrize("M,C", [(64, 256), (1000, 4096), (77, 300), (33, 40)])
+def test_hp_split_both_orientations_in_one_pass_is_bitwise_two_splits(M, C):
+    """rnnt_hip_hp_split_both (row maxima and column maxima given) writes exactly the planes the row-major and the transposed
+    rnnt_hip_hp_split write — ragged M and C (zero fill of the padded k range in both orientations)."""
+    from rnntransducer_amd import _lib
+    from rnntransducer_amd.ops import HpTensor, _addr, _stream, hp_split
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * torch.exp(torch.empty(M, 1).uniform_(-9, 2, generator=g))).cuda()
+    x[M // 2] = 0                                   # an all-zero row (a padded frame)
+    rm, tr = hp_split(x), hp_split(x, transpose=True)
+    rm2, tr2 = HpTensor(M, C, x.device), HpTensor(C, M, x.device)
+    rm2.planes.fill_(0x5A)
+    tr2.planes.fill_(0x5A)
+    _lib.check(_lib.lib().rnnt_hip_hp_split_both(_addr(x), M, C, C, _addr(rm.amax), _addr(tr.amax), _addr(rm2.planes), _addr(tr2.planes),
+                                                 _stream()), "hp_split_both")
+    n_rm, n_tr = _lib.lib().rnnt_hip_hp_bytes(M, C), _lib.lib().rnnt_hip_hp_bytes(C, M)
+    assert torch.equal(rm2.planes[:n_rm], rm.planes[:n_rm])
+    assert torch.equal(tr2.planes[:n_tr], tr.planes[:n_tr])
