@@ -15,6 +15,12 @@ SOURCES = ["api.hip", "gemm.hip", "gemm_hp.hip", "loss.hip", "lstm.hip", "lstm5.
 LIB = os.path.join(HERE, "librnnt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + HERE, "-Wno-unused-result"]
+# Per-file extras (none by default).  Tried for lstm5.hip: -mllvm -amdgpu-mfma-vgpr-form (no MFMA accumulator in an AGPR: one wave issues a
+# v_mfma_f32_16x16x32_f16 with an AGPR accumulator every 25 cycles instead of every 20, tools/mfma_f16_rate_probe.hip) — the
+# recurrences then need 254 VGPRs and no AGPRs, and a c2 step takes 31.31 instead of 31.16 ms (paired runs): not used.
+EXTRA_FLAGS = {}
+if os.environ.get("RNNT_BUILD_VGPR_FORM"):
+    EXTRA_FLAGS = {"lstm5.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale() -> bool:
@@ -34,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(HERE, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
