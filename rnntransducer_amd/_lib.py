@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librnnt_hip.so")
+# RNNT_HIP_LIB: another build of the same library (A/B variants made by `csrc/build.py --variant`); still no fallback of any kind
+LIB_PATH = os.environ.get("RNNT_HIP_LIB") or os.path.join(_HERE, "csrc", "librnnt_hip.so")
 ABI_VERSION = 3   # RNNT_HIP_ABI_VERSION of include/rnnt_hip.h
 
 GEMM_GELU_A, GEMM_GELU_B, GEMM_ACCUM, GEMM_MUL_DGELU, GEMM_EXACT_F32 = 1, 2, 4, 8, 16

@@ -55,5 +55,37 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, defines, only=None) -> str:
+    """A/B builds for measurements: librnnt_hip_<name>.so with extra -D flags (objects under build/<name>/); load it with RNNT_HIP_LIB.
+    `only`: the sources the flags concern (the other objects are taken from the main build)."""
+    build()
+    out_dir = os.path.join(HERE, "build", name)
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(HERE, f"librnnt_hip_{name}.so")
+    procs, objs = [], []
+    for src in SOURCES:
+        if only and src not in only:
+            objs.append(os.path.join(HERE, src.replace(".hip", ".o")))
+            continue
+        obj = os.path.join(out_dir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [HIPCC] + FLAGS + list(defines) + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(HERE, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m rnntransducer_amd.csrc.build --variant NAME -DFOO=1 ...
+        i = sys.argv.index("--variant")
+        only = [a[len("--only="):].split(",") for a in sys.argv if a.startswith("--only=")]
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")], only[0] if only else None))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

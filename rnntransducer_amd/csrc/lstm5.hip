@@ -15,6 +15,13 @@
 //   2. h . W_hh^T on v_mfma_f32_16x16x32_f16 with half-pair operands (gemm_hp.hip's arithmetic): h in (-1, 1) scaled by 2^14,
 //      W_hh scaled by a power of two from the workgroup's own slice maximum; 3 products (lo.hi + hi.lo + hi.hi) instead of 6.
 //
+//   3. Exchange images are laid out [k / 4][row][k % 4] (forward: packed h; backward: per producer, [unit / 4][row][unit % 4]): the
+//      lanes of one gather instruction read, and the lanes of one publishing instruction write, ONE contiguous block instead of a
+//      16-byte piece per row 4 * Kp bytes apart (the poll traffic is re-issued every round, so its request count is what the
+//      hand-off costs: c2 forward 8.6 -> 8.0 ms, backward 10.0 -> 9.5 ms per training step).
+//   4. A step's stash stores and the next step's stash loads are issued AFTER the arrival of this step's operands, not behind the
+//      publication: between a publication and the arrival of the next operands a CU's memory queue holds the polls only.
+//
 // Correctness never depends on placement: stores are sc1 write-through unless the group is VERIFIED to sit on one XCD (then
 // plain stores stay in that L2), loads are always sc1 (bypass L1).  All spins are bounded and raise the status word.
 #include "lstm_shared.hpp"
@@ -170,8 +177,12 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
   int c_off = valid ? (int)((((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
   int y_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * H + oj) * 4) : OOB;
   const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
-  const int hx_off = (ownw && inrow) ? (brow * Kp + oj) * 4 : OOB;
-  const int gat_off = inrow ? (brow * Kp + wave * Kw + 8 * lq) * 4 : 0x7ffffff0;  // rows beyond the group read 0 and are not checked
+  // exchange image laid out [k / 4][row][k % 4]: the 16-byte chunks of one k-quad of all rows are adjacent, so the lanes of one
+  // gather instruction (rows 0..NBR-1 of one k-quad) read ONE contiguous NBR x 16 bytes and an owner wave's publication (4 units x
+  // NBR rows) is one contiguous block — instead of NBR requests 4 * Kp bytes apart
+  const int hx_off = (ownw && inrow) ? (((oj >> 2) * NBR + brow) * 4 + (oj & 3)) * 4 : OOB;
+  const int gat_off = inrow ? ((((wave * Kw + 8 * lq) >> 2) * NBR) + brow) * 16 : 0x7ffffff0;  // rows beyond the group read 0 and are not checked
+  const int gat_ks = 8 * NBR * 16, gat_hi = NBR * 16;   // next 32-deep k-step / second k-quad of the lane's 8 values
   unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
   const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
 
@@ -183,9 +194,9 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
     const __amdgpu_buffer_rsrc_t src = hx_rsrc[(s_next - 1) & 1];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      const int off = (wave * Kw + 32 * ks < H) ? gat_off + 128 * ks : OOB;
+      const int off = (wave * Kw + 32 * ks < H) ? gat_off + gat_ks * ks : OOB;
       raw[ks][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, off, 0, AUX_SC1));
-      raw[ks][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, off + 16, 0, AUX_SC1));
+      raw[ks][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, off + gat_hi, 0, AUX_SC1));
     }
   };
   auto tags_ok = [&](unsigned want) -> bool {
@@ -199,6 +210,17 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
     return !inrow || (bad & TAG_MASK) == 0u;
   };
   f32x4 xp = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_off, 0, 0));
+  // the previous step's stash, kept in registers until this step's operands have arrived: between a publication and the arrival
+  // of the next operands the CU's memory queue holds the operand loads only
+  i32x4 st_g = {0, 0, 0, 0};
+  int st_c = 0, st_y = 0, st_yd = 0, st_goff = OOB, st_coff = OOB, st_yoff = OOB;
+  f32x4 xp_next = {0.f, 0.f, 0.f, 0.f};
+  auto flush_stash = [&]() {
+    __builtin_amdgcn_raw_buffer_store_b128(st_g, g_rsrc, st_goff, 0, 0);
+    if constexpr (CELL == 0) __builtin_amdgcn_raw_buffer_store_b32(st_c, c_rsrc, st_coff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(st_y, y_rsrc, st_yoff, 0, 0);
+    if (p.ydrop) __builtin_amdgcn_raw_buffer_store_b32(st_yd, yd_rsrc, st_yoff, 0, 0);
+  };
   for (int s = 0; s < T; ++s) {
     const int t = (d == 0) ? s : T - 1 - s;
     f32x4 acc[MB];
@@ -212,6 +234,10 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
         ok = poll_tagged([&]() -> bool { issue_gather(s); return tags_ok(want); }, p.status);
       }
       DBG_STAMP(1);
+    }
+    xp_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
+    flush_stash();
+    if (s > 0) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         // de-interleave 8 packed dwords into the hi / lo operand fragments (k order kept), tag bit cleared
@@ -282,32 +308,27 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
         if (wave == 0) {
 #pragma unroll
           for (int gi = lane; gi < 16 * MB; gi += 64) {
-            const int r = gi / MB, q = gi % MB;
+            const int r = gi % 16, q = gi / 16;   // consecutive lanes -> consecutive rows of one k-quad: contiguous
             const i32x4 gran = *reinterpret_cast<const i32x4*>(pubs + r * HS + 4 * q);
-            __builtin_amdgcn_raw_buffer_store_b128(gran, hx_rsrc[s & 1], r < NBR ? (r * Kp + j0 + 4 * q) * 4 : OOB, 0, AUX_SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(gran, hx_rsrc[s & 1], r < NBR ? (((j0 >> 2) + q) * NBR + r) * 16 : OOB, 0, AUX_SC1);
           }
         }
       }
     }
     DBG_STAMP(4);   // reduce + cell math + publication
-    issue_gather(s + 1);   // first poll round of the next step, in flight under the stash stores below (unused after the last step)
-    // next step's gate pre-activations BEFORE the stash stores: memory operations retire in issue order, so a wait for this load
-    // (or for the gathered operands) never waits for the stores behind it
-    const f32x4 xp_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
-    // stash for the backward pass (and the layer output): not waited for until the NEXT step's operands are waited for
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gact), g_rsrc, g_off, 0, 0);
-    if constexpr (CELL == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c_state), c_rsrc, c_off, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hval), y_rsrc, y_off, 0, 0);
-    if (p.ydrop) {
-      const float hd = (hash_u32(p.seed, (unsigned long long)(unsigned)(y_off >> 2)) >= p.drop_thresh) ? hval * p.keep_scale : 0.f;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hd), yd_rsrc, y_off, 0, 0);
-    }
+    issue_gather(s + 1);   // first poll round of the next step (unused after the last step); this step's stash stays in registers until it has arrived
+    st_g = __builtin_bit_cast(i32x4, gact);
+    st_c = __builtin_bit_cast(int, c_state);
+    st_y = __builtin_bit_cast(int, hval);
+    if (p.ydrop) st_yd = __builtin_bit_cast(int, (hash_u32(p.seed, (unsigned long long)(unsigned)(y_off >> 2)) >= p.drop_thresh) ? hval * p.keep_scale : 0.f);
+    st_goff = g_off; st_coff = c_off; st_yoff = y_off;
     g_off += g_step;
     c_off += c_step;
     y_off += y_step;
     xp = xp_next;
     DBG_STAMP(5);
   }
+  flush_stash();
   return true;
   };
   const bool okrun = local ? run(std::true_type{}) : run(std::false_type{});
@@ -441,11 +462,14 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   constexpr int NPAIR = NBR * UQ, NQ = NT / NPAIR, NLD = (NCMAX + NQ - 1) / NQ;   // NC <= NCMAX; threads beyond NQ * NPAIR only help elsewhere
   const int gq = tid / NPAIR, gpr = tid % NPAIR;
   const bool gact = gq < NQ;
-  const int grow = gpr / UQ, guq = gpr % UQ;
-  const int gat_base = ((gq * NBR + grow) * Kp + j0 + 4 * guq) * 4;   // bytes; + NQ producers per visit
+  // one producer's image laid out [unit / 4][row][unit % 4] (16-byte granules of one unit quad of all rows adjacent): a publishing
+  // instruction (4 quads x NBR rows) writes one contiguous block, the gathering threads of one producer read one contiguous block
+  const int grow = gpr % NBR, guq = gpr / NBR;
+  const int gat_base = (((gq * (Kp >> 2)) + (j0 >> 2) + guq) * NBR + grow) * 16;
+  const int pub_base = lrow < NBR ? ((wg * (Kp >> 2) + 4 * wave * NMB + lq) * NBR + lrow) * 16 : OOB;
+  constexpr int pub_mb = 4 * NBR * 16;
+  auto pair_index = [](int row, int uq) { return uq * NBR + row; };
   const int gat_step = NQ * NBR * Kp * 4;
-  // publish: lane -> row lrow, units 16*(wave*NMB + mb) + 4*lq .. +3
-  const int pub_base = lrow < NBR ? ((wg * NBR + lrow) * Kp + 16 * wave * NMB + 4 * lq) * 4 : OOB;
   unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
   const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
 
@@ -477,6 +501,21 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
     c_p = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, T > 1 ? y_off + y_step : OOB, 0, 0));
   }
   float dyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, y_off, 0, 0));
+  // the previous step's stash (dG, row maxima), kept in registers until this step's partial sums have arrived; the next step's stash
+  // reads are issued there too: between a publication and the arrival of the next partial sums the CU's memory queue holds the
+  // gather loads only
+  i32x4 st_dg = {0, 0, 0, 0}, st_dgh = {0, 0, 0, 0};
+  int st_goff = OOB, st_t = 0;
+  unsigned st_rm = 0u;
+  f32x4 gt_n = {0.f, 0.f, 0.f, 0.f};
+  float ct_n = 0.f, cp_n = 0.f, dy_n = 0.f;
+  auto flush_stash = [&]() {
+    __builtin_amdgcn_raw_buffer_store_b128(st_dg, g_rsrc, st_goff, 0, 0);
+    if constexpr (CELL == 1) __builtin_amdgcn_raw_buffer_store_b128(st_dgh, a_rsrc, st_goff, 0, 0);
+    if constexpr (CELL != 1) {
+      if (p.rowmax && st_rm != 0u) atomicMax(p.rowmax + (long)st_t * B + b0 + tid, st_rm);
+    }
+  };
   for (int s = 0; s < T; ++s) {
     const int t = (d == 0) ? T - 1 - s : s;
     const bool active = valid && t < olen;
@@ -488,6 +527,17 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
       const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;
       if (!__all(tags_ok(want))) ok = poll_tagged([&]() -> bool { issue_gather(s); return tags_ok(want); }, p.status);
       DBG_STAMP(1);
+    }
+    gt_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
+    if constexpr (CELL == 0) {
+      ct_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 1 < T ? c_off + c_step : OOB, 0, 0));
+      cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 2 < T ? c_off + 2 * c_step : OOB, 0, 0));
+    } else if constexpr (CELL == 1) {
+      cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, s + 2 < T ? y_off + 2 * y_step : OOB, 0, 0));
+    }
+    dy_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, s + 1 < T ? y_off + y_step : OOB, 0, 0));
+    flush_stash();
+    if (s > 0) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         u32x4 v = gr[i];
@@ -505,7 +555,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
     if (owner) {
       float dh = active ? dyv : 0.f;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) dh += red[q * NPAIR + brow * UQ + ouq][oi];   // (threads with gq >= NQ wrote zeros: never read)
+      for (int q = 0; q < NQ; ++q) dh += red[q * NPAIR + pair_index(brow, ouq)][oi];   // (threads with gq >= NQ wrote zeros: never read)
       if (active) {
         if constexpr (CELL == 0) {
           const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
@@ -582,31 +632,20 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
           u32x4 out = __builtin_bit_cast(u32x4, acc[j] * ginv);
           out[0] = (out[0] & ~1u) | tag;
           out[2] = (out[2] & ~1u) | tag;
-          if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + 64 * (mb0 + j), 0, 0);
-          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + 64 * (mb0 + j), 0, AUX_SC1);
+          if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + pub_mb * (mb0 + j), 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + pub_mb * (mb0 + j), 0, AUX_SC1);
         }
       }
     }
     DBG_STAMP(4);  // scale + MFMA + publication
     issue_gather(s + 1);
-    // next step's stash reads BEFORE this step's stash store (memory operations retire in issue order)
-    const int gn = s + 1 < T ? g_off + g_step : OOB;
-    const f32x4 gt_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, gn, 0, 0));
-    float ct_n = 0.f, cp_n = 0.f;
-    if constexpr (CELL == 0) {
-      ct_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 1 < T ? c_off + c_step : OOB, 0, 0));
-      cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 2 < T ? c_off + 2 * c_step : OOB, 0, 0));
-    } else if constexpr (CELL == 1) {
-      cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, s + 2 < T ? y_off + 2 * y_step : OOB, 0, 0));
-    }
-    const float dy_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, s + 1 < T ? y_off + y_step : OOB, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dg4), g_rsrc, g_off, 0, 0);
-    if constexpr (CELL == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, dgh4), a_rsrc, g_off, 0, 0);
-    if constexpr (CELL != 1) {   // (GRU: input- and hidden-side gradients differ; its caller measures the rows itself)
-      if (p.rowmax && tid < NBR) {   // this workgroup's share of the frame rows' maxima (rowexp of this parity is cleared a step later)
-        const unsigned m = rowexp[(s & 1) * 16 + tid];
-        if (m != 0u && tid < p.Bg && b0 + tid < B) atomicMax(p.rowmax + (long)t * B + b0 + tid, m);
-      }
+    st_dg = __builtin_bit_cast(i32x4, dg4);
+    if constexpr (CELL == 1) st_dgh = __builtin_bit_cast(i32x4, dgh4);
+    st_goff = g_off;
+    st_t = t;
+    if constexpr (CELL != 1) {
+      st_rm = 0u;
+      if (p.rowmax && tid < NBR && tid < p.Bg && b0 + tid < B) st_rm = rowexp[(s & 1) * 16 + tid];   // (cleared a step later)
     }
     g_off += g_step;
     c_off += c_step;
@@ -614,6 +653,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
     gt = gt_n; c_t = ct_n; c_p = cp_n; dyv = dy_n;
     DBG_STAMP(5);  // gather issue + prefetch + stash
   }
+  flush_stash();
   return true;
   };
   const bool okrun = local ? run(std::true_type{}) : run(std::false_type{});
