@@ -235,8 +235,6 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
       }
       DBG_STAMP(1);
     }
-    xp_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
-    flush_stash();
     if (s > 0) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -258,6 +256,10 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
       }
       DBG_STAMP(2);
     }
+    // the previous step's stash and the next step's gate pre-activations: issued BEHIND this step's MFMAs (they execute while these
+    // instructions issue; in front of them the same five VMEM issues held the MFMAs back by 760 cycles per step)
+    xp_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
+    flush_stash();
     if (!ok) *abort_lds = 1;   // benign race: any wave that gave up makes the whole workgroup leave after the barrier
     f32x4* pp = part + (s & 1) * (NWV * MB * 64);
 #pragma unroll
@@ -316,7 +318,9 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
       }
     }
     DBG_STAMP(4);   // reduce + cell math + publication
-    issue_gather(s + 1);   // first poll round of the next step (unused after the last step); this step's stash stays in registers until it has arrived
+    // first poll round of the next step (unused after the last step); this step's stash stays in registers until it has arrived.
+    // (A pause in front of it — s_sleep 6 / 8 — gains 2 % at c2 and c5 and loses 1-3 % at c3: not taken.)
+    issue_gather(s + 1);
     st_g = __builtin_bit_cast(i32x4, gact);
     st_c = __builtin_bit_cast(int, c_state);
     st_y = __builtin_bit_cast(int, hval);
@@ -459,7 +463,10 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
 
   // gather: thread -> (row, unit quad) pair gpr and producer class gq; it sums the partial slices of producers gq, gq + NQ, ...
-  constexpr int NPAIR = NBR * UQ, NQ = NT / NPAIR, NLD = (NCMAX + NQ - 1) / NQ;   // NC <= NCMAX; threads beyond NQ * NPAIR only help elsewhere
+  // gathering threads: all of them, except in the H = 512 form with 8 waves, where the first 4 waves gather (as in the 4-wave form) and
+  // the other 4 only share the MFMA + publication phase
+  constexpr int NTG = (NWV == 8 && MB == 4 && NCMAX == 32) ? 256 : NT;
+  constexpr int NPAIR = NBR * UQ, NQ = NTG / NPAIR, NLD = (NCMAX + NQ - 1) / NQ;   // NC <= NCMAX; threads beyond NQ * NPAIR only help elsewhere
   const int gq = tid / NPAIR, gpr = tid % NPAIR;
   const bool gact = gq < NQ;
   // one producer's image laid out [unit / 4][row][unit % 4] (16-byte granules of one unit quad of all rows adjacent): a publishing
@@ -528,15 +535,17 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
       if (!__all(tags_ok(want))) ok = poll_tagged([&]() -> bool { issue_gather(s); return tags_ok(want); }, p.status);
       DBG_STAMP(1);
     }
-    gt_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
-    if constexpr (CELL == 0) {
-      ct_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 1 < T ? c_off + c_step : OOB, 0, 0));
-      cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 2 < T ? c_off + 2 * c_step : OOB, 0, 0));
-    } else if constexpr (CELL == 1) {
-      cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, s + 2 < T ? y_off + 2 * y_step : OOB, 0, 0));
-    }
-    dy_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, s + 1 < T ? y_off + y_step : OOB, 0, 0));
-    flush_stash();
+    auto stash_traffic = [&]() {   // the next step's stash reads, the previous step's stash stores (issued inside the MFMA phase below)
+      gt_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
+      if constexpr (CELL == 0) {
+        ct_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 1 < T ? c_off + c_step : OOB, 0, 0));
+        cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s + 2 < T ? c_off + 2 * c_step : OOB, 0, 0));
+      } else if constexpr (CELL == 1) {
+        cp_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, s + 2 < T ? y_off + 2 * y_step : OOB, 0, 0));
+      }
+      dy_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, s + 1 < T ? y_off + y_step : OOB, 0, 0));
+      flush_stash();
+    };
     if (s > 0) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
@@ -635,6 +644,9 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
           if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + pub_mb * (mb0 + j), 0, 0);
           else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + pub_mb * (mb0 + j), 0, AUX_SC1);
         }
+        // behind the first group's MFMAs and publication stores: these VMEM instructions issue while the second group's MFMAs
+        // execute.  (Right behind the poll they delayed the whole local chain: 9.5 -> 8.4 ms of backward recurrences per c2 step.)
+        if (mb0 == 0) stash_traffic();
       }
     }
     DBG_STAMP(4);  // scale + MFMA + publication
@@ -776,6 +788,14 @@ int lstm5_bwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
     else if (k.Kp == 1024) B58(8);
     else set_error("lstm_bwd5: H = %d not supported", k.H);
 #undef B58
+    return rc;
+  }
+  if (k.H == 512 && getenv("RNNT_LSTM_BWD5_8W")) {   // 8 waves x 4 output blocks (two waves per SIMD share the MFMA pipe)
+    const int threads = 512;
+    const size_t lds = (size_t)512 * 16 + 16 * (32 * 2 + 4) * 4 + 32 * 4 + 32 + 16;
+    if (cell == RNNT_CELL_LSTM) B5Q(4, 0, 8, 4, 32);
+    else if (cell == RNNT_CELL_GRU) B5Q(4, 1, 8, 4, 32);
+    else B5Q(4, 2, 8, 4, 32);
     return rc;
   }
   const int threads = 256;

@@ -9,7 +9,7 @@ from rnntransducer_amd import _lib
 from rnntransducer_amd.ops import LstmStackFn, _addr, _stream
 from rnntransducer_amd.networks.rnn import HipLSTM
 
-T, B, I, H = 1000, 32, 1024, 512
+T, B, I, H = 1000, int(os.environ.get("PROBE_B", "32")), 1024, int(os.environ.get("PROBE_H", "512"))
 torch.manual_seed(0)
 lstm = HipLSTM(I, H, 1, bidirectional=True).cuda()
 x = torch.randn(T, B, I, device="cuda", requires_grad=True)
