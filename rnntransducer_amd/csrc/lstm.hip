@@ -2036,7 +2036,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   const bool grouped = w.hp && hp_in && T > 1 && !gru && D <= 2 && (xcd_skip != 0u || getenv("RNNT_GEMM_HP_GROUP")) && !getenv("RNNT_GEMM_HP_NO_GROUP");
   // 3. dW_ih' = dG^T . X  (both directions at once), un-permute rows into torch layout
   {
-    if (hp_in) {
+    // (a narrow input — the 80 mel bins of layer 0 — still goes to the half-pair kernel: one 256-wide tile column, split over K)
+    const bool x_plain = d->x_sb == I && d->x_st == (int64_t)B * I;
+    if (hp_in || (w.hp && I >= 32 && x_plain && !getenv("RNNT_GEMM_HP_NO_NARROW"))) {
       if (d->x_abs_bound > 0.f) {   // bounded input (the dropped output of the layer below): its bound is the scale, no pass over x
         uint32_t bits;
         memcpy(&bits, &d->x_abs_bound, 4);
