@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
       DBG_STAMP(2);
     }
     // the previous step's stash and the next step's gate pre-activations: issued BEHIND this step's MFMAs (they execute while these
-    // instructions issue; in front of them the same five VMEM issues held the MFMAs back by 760 cycles per step)
+    // instructions issue; in front of them — or between the two k-steps' MFMAs — the same five VMEM issues cost 760 cycles per step)
     xp_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
     flush_stash();
     if (!ok) *abort_lds = 1;   // benign race: any wave that gave up makes the whole workgroup leave after the barrier
@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
       }
       const unsigned tag = (((unsigned)s >> 1) & 1u) ^ 1u;
       // groups of 4 output blocks: 4 independent accumulators between dependent MFMAs
-      constexpr int GB = NMB % 4 == 0 ? 4 : 2;   // NMB is 2, 4, 6 or 8
+      constexpr int GB = (NMB % 4 == 0 && NMB > 4) ? 4 : 2;   // NMB is 2, 4, 6 or 8; at least two groups when NMB >= 4 (stash traffic behind the first)
 #pragma unroll
       for (int mb0 = 0; mb0 < NMB; mb0 += GB) {
         f32x4 acc[GB];
@@ -646,6 +646,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
         }
         // behind the first group's MFMAs and publication stores: these VMEM instructions issue while the second group's MFMAs
         // execute.  (Right behind the poll they delayed the whole local chain: 9.5 -> 8.4 ms of backward recurrences per c2 step.)
+        // (behind the LAST group's MFMAs, or behind the whole phase: 9.35 instead of 8.4 ms)
         if (mb0 == 0) stash_traffic();
       }
     }
