@@ -749,7 +749,21 @@ extern "C" int rnnt_hip_gemm_f32(const rnnt_gemm_desc* d, void* stream) {
   const int bks = BK;  // (a K-tile depth of 32 with 128x128 tiles was measured slower: DESIGN.md 4.4; the kernel template still takes it)
   const int bn = pick_bn(d->M, d->N);
   // 256x256 tiles / 512 threads / one workgroup per CU for the split-bf16 form when the output is large in both directions
-  const bool big = mode == 6 && d->M >= 256 && d->N >= 256 && !getenv("RNNT_GEMM_NO256");
+  // (a 256x256 tile walks its K-tiles alone: with fewer than 64 workgroups even after split-K — the prediction net's 1312-row
+  //  products — the 128-row tilings finish sooner: 112 -> 30 us for 1312 x 512 x 512)
+  bool big = mode == 6 && d->M >= 256 && d->N >= 256 && !getenv("RNNT_GEMM_NO256");
+  if (big && !getenv("RNNT_GEMM_256_ALWAYS")) {
+    const long t256 = ceil_div(d->M, 256) * ceil_div(d->N, 256);
+    long sp = 1;
+    if (d->workspace && d->K >= 8 * BK) {
+      sp = d->K / (8 * BK);
+      const long by_ws = (long)(d->workspace_bytes / ((size_t)d->M * d->N * 4));
+      if (sp > by_ws) sp = by_ws;
+      if (sp > 64) sp = 64;
+      if (sp < 1) sp = 1;
+    }
+    if (t256 * sp < 64) big = false;
+  }
   const int tiles = big ? (int)(ceil_div(d->M, 256) * ceil_div(d->N, 256)) : (int)(ceil_div(d->M, BM) * ceil_div(d->N, bn));
   const int slots = big ? 256 : 512;  // workgroups the chip holds at once
   // split-K when the output has too few tiles to fill 256 CUs and K is deep (weight-gradient GEMMs):

@@ -89,12 +89,15 @@ def lstm_status_check(device=None) -> None:
 # --------------------------------------------------------------------------------------------------
 def gemm(M: int, N: int, K: int, A: torch.Tensor, B: torch.Tensor, Cout: torch.Tensor, *, a_off=0, a_div=BIG, a_so=0,
          a_si=None, a_sk=1, a_mc=False, a_rowidx=None, b_off=0, b_sn=None, b_sk=1, c_off=0, c_div=BIG, c_so=0, c_si=None,
-         bias=None, aux=None, flags=0, split_k=False) -> None:
+         bias=None, aux=None, flags=0, split_k=None) -> None:
     """C(m,n) = sum_k A(m,k) B(k,n) (+bias) — see include/rnnt_hip.h for the operand maps.
-    split_k=True hands the kernel a slab workspace so small-output / deep-K products (weight gradients) fill the chip."""
+    split_k=True hands the kernel a slab workspace so small-output / deep-K products (weight gradients) fill the chip;
+    None (default): do so when the output is small (<= 2^21 elements: the prediction net's and the joint's products)."""
     _need_gpu(A, B, Cout)
     d = GemmDesc()
     ws = None
+    if split_k is None:
+        split_k = M * N <= (1 << 21)
     if split_k:
         nws = _lib.lib().rnnt_hip_gemm_workspace_bytes(M, N, K)
         if nws:
