@@ -1691,6 +1691,7 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->xcc = w.flags + 16 + w.nflags;
   k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
   k->hw_math = getenv("RNNT_LSTM_EXACT_MATH") ? 0 : 1;
+  k->pause = 0;
   k->colmax = k->colmax_h = nullptr;
   k->rowmax = nullptr;
 }

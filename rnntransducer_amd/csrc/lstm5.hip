@@ -25,6 +25,7 @@
 // Correctness never depends on placement: stores are sc1 write-through unless the group is VERIFIED to sit on one XCD (then
 // plain stores stay in that L2), loads are always sc1 (bypass L1).  All spins are bounded and raise the status word.
 #include "lstm_shared.hpp"
+#include <string.h>
 
 namespace rnnt {
 namespace {
@@ -320,6 +321,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
     DBG_STAMP(4);   // reduce + cell math + publication
     // first poll round of the next step (unused after the last step); this step's stash stays in registers until it has arrived.
     // (A pause in front of it — s_sleep 6 / 8 — gains 2 % at c2 and c5 and loses 1-3 % at c3: not taken.)
+    for (int i = 0; i < (p.pause & 255); ++i) __builtin_amdgcn_s_sleep(1);
     issue_gather(s + 1);
     st_g = __builtin_bit_cast(i32x4, gact);
     st_c = __builtin_bit_cast(int, c_state);
@@ -696,6 +698,433 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   }
 }
 
+// ================================================================================================
+// backward, ONE barrier per step (H = 128..512: 4 waves x 16 units, <= 32 producers per group; lstm_bwd5_kernel keeps the other shapes
+// and is the A/B partner: RNNT_LSTM_BWD5_2B=1).  Same decomposition, exchange protocol and arithmetic as lstm_bwd5_kernel; what
+// changed is who does what inside the workgroup (profiles/r02_lstm_phase_cycles_v5_final.txt: of 4 521 cycles per step 748 were
+// "partial sums + barrier" and 2 021 "scale + MFMA + publication", where every wave converted the whole 16 x 64 dG image to f16 pairs):
+//   1. Wave w gathers AND owns exchange rows w*BQ .. w*BQ+BQ-1: lane = class * PPW + (unit quad * BQ + row), class = the producers
+//      c, c + NQ, ... the lane sums in registers.  The sum over classes is a butterfly over lane bits (DPP rotations inside a row of
+//      16 lanes, v_permlane16/32_swap across rows) — no LDS round trip, no barrier; lanes of class 0..3 then own the cell of unit
+//      4 * quad + class.  The exchange image orders a block's granules [row / BQ][quad][row % BQ] so that such a wave still reads one
+//      contiguous run per producer and a publishing instruction still writes one contiguous block.
+//   2. The row's maximum over the workgroup's 64 gate columns (the f16 scale) is the same kind of butterfly (the 16 owners of a row
+//      sit in one wave), so the cell owner scales and splits ITS 4 values and the LDS image holds ready f16 operand fragments: the
+//      MFMA phase starts with 4 ds_read_b128 instead of 16 conversions per lane in every wave.
+// dynamic LDS: img[2 parities][hi | lo][16][GLD] f16 | rowexp[2][16] | wmax[8] | abort
+// ================================================================================================
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+// x[l] combined with x[l ^ 16] / x[l ^ 32] (gfx950 v_permlane16_swap / v_permlane32_swap: no LDS crossbar)
+// v_permlane16_swap / v_permlane32_swap (gfx950): rows 1, 3 of a <-> rows 0, 2 of b / lanes 32..63 of a <-> lanes 0..31 of b.  Inline
+// asm: hipcc 7.2 models both results of __builtin_amdgcn_permlane*_swap as the first one (r[0] + r[1] became v_add v2, v2, v2).  The
+// s_nop cover the VALU-write -> permlane-read wait states the hazard recogniser cannot see inside an asm block.
+__device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xadd16(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  unsigned r[2] = {u, u};
+  permlane16_swap(r[0], r[1]);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ float xadd32(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  unsigned r[2] = {u, u};
+  permlane32_swap(r[0], r[1]);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ unsigned xmax16(unsigned u) {
+  unsigned r[2] = {u, u};
+  permlane16_swap(r[0], r[1]);
+  return r[0] > r[1] ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned xmax32(unsigned u) {
+  unsigned r[2] = {u, u};
+  permlane32_swap(r[0], r[1]);
+  return r[0] > r[1] ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ float radd(float x, unsigned rot) { return x + __builtin_bit_cast(float, rot); }
+
+template <int NMB, int BQ, int CELL, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV) lstm_bwd5f_kernel(const LstmK p) {
+  constexpr int NGATE = CELL == 0 ? 4 : (CELL == 1 ? 3 : 1);
+  constexpr int HS = 16, NT = 64 * NWV, KSB = 2, NCMAX = 32;
+  static_assert(NWV == 4 || NWV == 8, "waves 0..3 gather and own the cells; waves 4..7 (if any) only share the MFMA + publication phase");
+  constexpr int NBR = 4 * BQ;        // exchange rows of the group
+  constexpr int RPW = BQ;            // rows per gathering wave
+  constexpr int PPW = 4 * RPW;       // (row, unit quad) pairs per wave: 4, 8, 16
+  constexpr int NQ = 64 / PPW;       // producer classes = lanes per pair: 16, 8, 4
+  constexpr int NLD = NCMAX / NQ;    // granules a lane sums in registers: 2, 4, 8
+  constexpr int GLD = 32 * KSB + 8;  // f16 per image row (16-byte aligned rows)
+  constexpr int OOB = 0x7ffffff0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  _Float16* img = reinterpret_cast<_Float16*>(smem);                 // [2][2][16][GLD]
+  unsigned* rowexp = reinterpret_cast<unsigned*>(img + 2 * 2 * 16 * GLD);
+  float* wmax = reinterpret_cast<float*>(rowexp + 32);
+  int* abort_lds = reinterpret_cast<int*>(wmax + 8);
+
+  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NG = D * p.G;
+  const int gid = blockIdx.x % p.NGL, wg = blockIdx.x / p.NGL;
+  if (gid >= NG) return;
+  const int d = gid / p.G, g = gid % p.G;
+  const int b0 = g * p.Bg, j0 = wg * HS;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  // W_hh slice as the A operand (as lstm_bwd5_kernel): lane -> output unit u = 16*(wave*NMB + mb) + lrow,
+  // k = 32*ks + 8*lq + e = own gate column 4*unit + gate  ->  W_hh[gate*H + j0 + (k>>2)][u]
+  f16x8 whi[NMB][KSB], wlo[NMB][KSB];
+  float w_inv;
+  {
+    const float* W = p.w_hh[d];
+    f32x4 raw[NMB][KSB][2];
+    float m = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const int u = 16 * (wave * NMB + mb) + lrow;
+#pragma unroll
+      for (int ks = 0; ks < KSB; ++ks) {
+        const int c = 32 * ks + 8 * lq;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (u < H) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (e < NGATE) {
+              lo[e] = W[(long)(e * H + j0 + (c >> 2)) * H + u];
+              hi[e] = W[(long)(e * H + j0 + (c >> 2) + 1) * H + u];
+            }
+          }
+        }
+        raw[mb][ks][0] = lo;
+        raw[mb][ks][1] = hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) wmax[wave] = m;
+    if (tid == 0) *abort_lds = 0;
+    if (tid < 32) rowexp[tid] = 0u;
+    for (int i = tid; i < 2 * 2 * 16 * GLD / 2; i += NT) reinterpret_cast<unsigned*>(img)[i] = 0u;
+    __syncthreads();
+    m = wmax[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) m = fmaxf(m, wmax[w]);
+    int eb = (int)((__float_as_uint(m) >> 23) & 255u);
+    eb = eb < 15 ? 15 : eb;
+    const float wscale = m > 0.f ? __uint_as_float((unsigned)(268 - eb) << 23) : 1.f;
+    w_inv = m > 0.f ? __uint_as_float((unsigned)(eb - 14) << 23) : 1.f;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < KSB; ++ks) split8h(raw[mb][ks][0], raw[mb][ks][1], wscale, whi[mb][ks], wlo[mb][ks]);
+  }
+
+  const long px_bytes = (long)p.NC * NBR * Kp * 4;  // one (parity, group) image: [producer][Kp / 16 blocks][4 * NBR granules]
+  __amdgpu_buffer_rsrc_t px_rsrc[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    px_rsrc[par] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.hx) + ((long)par * NG + gid) * px_bytes, 0, (int)px_bytes, RSRC_FLAGS);
+
+  // lane = cls * PPW + uq * RPW + rr: exchange row wave*RPW + rr, unit quad uq, producer class cls; classes 0..3 own the cells
+  const int rr = lane % RPW, ouq = (lane / RPW) & 3, cls = lane / PPW;
+  const bool gw = wave < 4;          // gathering / cell-owning wave (scalar)
+  const bool owner = gw && cls < 4;
+  const int oi = cls & 3;
+  const int brow = wave * RPW + rr, ob = b0 + brow, oj = j0 + 4 * ouq + oi;
+  const bool valid = owner && brow < p.Bg && ob < B;
+  const int olen = valid ? p.lens[ob] : 0;
+  float dc_carry = 0.f;
+  f32x4 db_acc = {0.f, 0.f, 0.f, 0.f}, dbh_acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 cmx = {0.f, 0.f, 0.f, 0.f}, cmxh = {0.f, 0.f, 0.f, 0.f};
+  const int t_first = (d == 0) ? T - 1 : 0;
+  const int tdir = (d == 0) ? -1 : 1;
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)T * B * D * 4 * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, CELL == 1 ? (int)((long)T * B * D * 4 * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * T * B * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
+  const bool addressed = valid;
+  int g_off = addressed ? (int)(((((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj) * 4) : OOB;
+  int c_off = addressed ? (int)((((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
+  int y_off = addressed ? (int)(((((long)t_first * B + ob) * D + d) * H + oj) * 4) : OOB;
+  const int g_step = addressed ? tdir * B * D * 4 * H * 4 : 0, c_step = addressed ? tdir * H * B * 4 : 0, y_step = addressed ? tdir * B * D * H * 4 : 0;
+
+  // exchange image of one producer: [unit / 16][row / RPW][unit quad][row % RPW] granules of 16 bytes (4 units of one row)
+  const int gat_base = ((cls * (Kp >> 2) + (j0 >> 2)) * NBR + wave * PPW + (lane % PPW)) * 16;
+  const int gat_step = NQ * NBR * Kp * 4;
+  const int pub_base = lrow < NBR ? ((wg * (Kp >> 2) + 4 * wave * NMB) * NBR + ((lrow / RPW) * 4 + lq) * RPW + lrow % RPW) * 16 : OOB;
+  constexpr int pub_mb = 4 * NBR * 16;
+  // this workgroup consumes block wg of every producer: wave wg / NMB publishes it in its MFMA group (wg % NMB) / GB
+  const int my_pause = ((wg % NMB) < ((NMB % 4 == 0 && NMB > 4) ? 4 : 2)) ? (p.pause & 255) : ((p.pause >> 8) & 255);
+  const int img_w = brow * GLD + 4 * (4 * ouq + oi);   // the owner's 4 gate columns (f16 index inside one [16][GLD] plane)
+  const int img_r = lrow * GLD + 8 * lq;
+  unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dlast = clock64();
+  const bool local = p.allow_local && group_is_xcd_local(p.xcc + gid * p.NC, p.NC, wg, p.status, abort_lds);
+
+  auto run = [&](auto local_tag) -> bool {
+  constexpr bool LOCAL = decltype(local_tag)::value;
+  u32x4 gr[NLD];
+  auto issue_gather = [&](int s_next) {   // partials published at step s_next - 1
+    const __amdgpu_buffer_rsrc_t src = px_rsrc[(s_next - 1) & 1];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const bool okp = gw && cls + NQ * i < p.NC;
+      gr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, okp ? gat_base + i * gat_step : OOB, 0, AUX_SC1));
+    }
+  };
+  auto tags_ok = [&](unsigned want) -> bool {
+    unsigned bad = 0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (gw && cls + NQ * i < p.NC) bad |= (gr[i][0] ^ want) | (gr[i][2] ^ want);
+    return (bad & 1u) == 0u;
+  };
+  // the stash of a step (activated gates, c_t, c_{t-1}, dy) is fetched TWO steps ahead into the register set of the step's parity
+  // (the loop body is instantiated twice, so no register is moved while its load is in flight): the reads come from HBM (the
+  // stash of a layer is 0.8 GB at c2) and one step of 2 us does not cover that latency behind the poll traffic
+  struct Stash { f32x4 gt; float c_t, c_p, dyv; };
+  auto load_stash = [&](Stash& st, int ahead, int s_of) {   // the stash of step s_of = (current step) + ahead
+    const bool in = s_of < T;
+    st.gt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, in ? g_off + ahead * g_step : OOB, 0, 0));
+    st.c_t = st.c_p = 0.f;
+    if constexpr (CELL == 0) {
+      st.c_t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, in ? c_off + ahead * c_step : OOB, 0, 0));
+      st.c_p = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, s_of + 1 < T ? c_off + (ahead + 1) * c_step : OOB, 0, 0));
+    } else if constexpr (CELL == 1) {
+      st.c_p = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rsrc, s_of + 1 < T ? y_off + (ahead + 1) * y_step : OOB, 0, 0));
+    }
+    st.dyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, in ? y_off + ahead * y_step : OOB, 0, 0));
+  };
+  auto drop = [&](float dyv, int ahead) -> float {   // the dropout mask of the layer output, regenerated from (seed, element index)
+    return (hash_u32(p.seed, (unsigned long long)(unsigned)((y_off + ahead * y_step) >> 2)) >= p.drop_thresh) ? dyv * p.keep_scale : 0.f;
+  };
+  // (Tried: waves 4..7 of the 8-wave form fetching the stash for waves 0..3 through an LDS ring, so that no polling wave has an
+  //  HBM-latency load in its in-order return queue: 8.76 instead of 7.95 ms of backward recurrences per c2 step.)
+  Stash stA, stB;
+  load_stash(stA, 0, 0);
+  load_stash(stB, 1, 1);
+  i32x4 st_dg = {0, 0, 0, 0}, st_dgh = {0, 0, 0, 0};
+  int st_goff = OOB, st_t = 0;
+  unsigned st_rm = 0u;
+  auto flush_stash = [&]() {
+    __builtin_amdgcn_raw_buffer_store_b128(st_dg, g_rsrc, st_goff, 0, 0);
+    if constexpr (CELL == 1) __builtin_amdgcn_raw_buffer_store_b128(st_dgh, a_rsrc, st_goff, 0, 0);
+    if constexpr (CELL != 1) {
+      if (p.rowmax && st_rm != 0u) atomicMax(p.rowmax + (long)st_t * B + b0 + tid, st_rm);
+    }
+  };
+  auto step = [&](const int s, Stash& cur) -> bool {
+    f32x4& gt = cur.gt;
+    float &c_t = cur.c_t, &c_p = cur.c_p, &dyv = cur.dyv;
+    const int t = (d == 0) ? T - 1 - s : s;
+    const int par = s & 1;
+    const bool active = valid && t < olen;
+    if (p.ydrop) dyv = drop(dyv, 0);
+    DBG_STAMP(0);
+    f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (s > 0) {
+      const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;
+      if (!__all(tags_ok(want))) ok = poll_tagged([&]() -> bool { issue_gather(s); return tags_ok(want); }, p.status);
+      DBG_STAMP(1);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        u32x4 v = gr[i];
+        v[0] &= ~1u;
+        v[2] &= ~1u;
+        gsum += __builtin_bit_cast(f32x4, v);   // producers beyond NC loaded zeros
+      }
+      // sum over the producer classes: lane bits log2(PPW) .. 5
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = gsum[e];
+        if constexpr (PPW == 4) x = radd(x, dpp_u32<0x124>(__builtin_bit_cast(unsigned, x)));   // row_ror:4
+        if constexpr (PPW <= 8) x = radd(x, dpp_u32<0x128>(__builtin_bit_cast(unsigned, x)));   // row_ror:8
+        x = xadd16(x);
+        x = xadd32(x);
+        gsum[e] = x;
+      }
+    }
+    auto stash_traffic = [&]() {   // this step's registers are free (the cell math is done): the stash of step s + 2, and the previous step's stores
+      load_stash(cur, 2, s + 2);
+      flush_stash();
+    };
+    DBG_STAMP(2);  // partial sums (registers + lane butterfly)
+    f32x4 dg4 = {0.f, 0.f, 0.f, 0.f}, dgh4 = {0.f, 0.f, 0.f, 0.f};
+    {
+      float dh = (active ? dyv : 0.f) + (oi == 0 ? gsum[0] : (oi == 1 ? gsum[1] : (oi == 2 ? gsum[2] : gsum[3])));
+      if (active) {
+        if constexpr (CELL == 0) {
+          const float ig = gt[0], fg = gt[1], gg = gt[2], og = gt[3];
+          const float tc = tanh_hw(c_t);
+          const float dc = dh * og * (1.f - tc * tc) + dc_carry;
+          dg4[0] = dc * gg * ig * (1.f - ig);
+          dg4[1] = dc * c_p * fg * (1.f - fg);
+          dg4[2] = dc * ig * (1.f - gg * gg);
+          dg4[3] = dh * tc * og * (1.f - og);
+          dc_carry = dc * fg;
+          dgh4 = dg4;
+        } else if constexpr (CELL == 1) {
+          const float rg = gt[0], zg = gt[1], ng = gt[2], hn = gt[3];
+          dh += dc_carry;
+          const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+          const float dz_pre = dh * (c_p - ng) * zg * (1.f - zg);
+          const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+          dg4 = (f32x4){dr_pre, dz_pre, dn_pre, 0.f};
+          dgh4 = (f32x4){dr_pre, dz_pre, dn_pre * rg, 0.f};
+          dc_carry = dh * zg;
+        } else {
+          const float hv = gt[0];
+          dg4 = (f32x4){dh * (1.f - hv * hv), 0.f, 0.f, 0.f};
+          dgh4 = dg4;
+        }
+      } else {
+        dc_carry = 0.f;
+      }
+      db_acc += dg4;
+      if constexpr (CELL == 1) dbh_acc += dgh4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cmx[e] = fmaxf(cmx[e], fabsf(dg4[e]));
+        if constexpr (CELL == 1) cmxh[e] = fmaxf(cmxh[e], fabsf(dgh4[e]));
+      }
+      // the row's maximum over the 64 own gate columns: its 16 owners are lanes of this wave (bits log2(RPW) .. log2(RPW)+3)
+      unsigned mxb = umax(umax(__float_as_uint(dgh4[0]) & 0x7fffffffu, __float_as_uint(dgh4[1]) & 0x7fffffffu),
+                          umax(__float_as_uint(dgh4[2]) & 0x7fffffffu, __float_as_uint(dgh4[3]) & 0x7fffffffu));
+      if constexpr (RPW == 1) mxb = umax(mxb, dpp_u32<0xB1>(mxb));    // quad_perm [1,0,3,2]
+      if constexpr (RPW <= 2) mxb = umax(mxb, dpp_u32<0x4E>(mxb));    // quad_perm [2,3,0,1]
+      mxb = umax(mxb, dpp_u32<0x124>(mxb));                          // row_ror:4, row_ror:8 -> lanes l, l+4, l+8, l+12
+      mxb = umax(mxb, dpp_u32<0x128>(mxb));
+      if constexpr (RPW >= 2) mxb = xmax16(mxb);
+      if constexpr (RPW == 4) mxb = xmax32(mxb);
+      int eb = (int)((mxb >> 23) & 255u);
+      eb = eb < 15 ? 15 : eb;
+      const float gscale = mxb != 0u ? __uint_as_float((unsigned)(268 - eb) << 23) : 1.f;
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      f16x4 h4, l4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = dgh4[e] * gscale;
+        const _Float16 h = (_Float16)v;
+        h4[e] = h;
+        l4[e] = (_Float16)(v - (float)h);
+      }
+      if (owner) {
+        _Float16* dst = img + par * (2 * 16 * GLD) + img_w;
+        *reinterpret_cast<f16x4*>(dst) = h4;
+        *reinterpret_cast<f16x4*>(dst + 16 * GLD) = l4;
+        if (lane < RPW) rowexp[par * 16 + brow] = mxb;
+      }
+    }
+    if (!ok) *abort_lds = 1;
+    __syncthreads();
+    if (*abort_lds != 0) return false;
+    DBG_STAMP(3);  // cell math + f16 image + barrier
+    {
+      const unsigned rmax = rowexp[par * 16 + lrow];
+      int eb = (int)((rmax >> 23) & 255u);
+      eb = eb < 15 ? 15 : eb;
+      const float ginv = (rmax != 0u ? __uint_as_float((unsigned)(eb - 14) << 23) : 1.f) * w_inv;
+      f16x8 ghi[KSB], glo[KSB];
+      const _Float16* src = img + par * (2 * 16 * GLD) + img_r;
+#pragma unroll
+      for (int ks = 0; ks < KSB; ++ks) {
+        ghi[ks] = *reinterpret_cast<const f16x8*>(src + 32 * ks);
+        glo[ks] = *reinterpret_cast<const f16x8*>(src + 16 * GLD + 32 * ks);
+      }
+      const unsigned tag = (((unsigned)s >> 1) & 1u) ^ 1u;
+      constexpr int GB = (NMB % 4 == 0 && NMB > 4) ? 4 : 2;
+#pragma unroll
+      for (int mb0 = 0; mb0 < NMB; mb0 += GB) {
+        f32x4 acc[GB];
+#pragma unroll
+        for (int j = 0; j < GB; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+#pragma unroll
+          for (int j = 0; j < GB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[mb0 + j][ks], ghi[ks], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < GB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[mb0 + j][ks], glo[ks], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < GB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[mb0 + j][ks], ghi[ks], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+          u32x4 out = __builtin_bit_cast(u32x4, acc[j] * ginv);
+          out[0] = (out[0] & ~1u) | tag;
+          out[2] = (out[2] & ~1u) | tag;
+          if constexpr (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + pub_mb * (mb0 + j), 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), px_rsrc[s & 1], pub_base + pub_mb * (mb0 + j), 0, AUX_SC1);
+        }
+        if (mb0 == 0 && gw) stash_traffic();   // behind the first group's MFMAs and publication stores (as lstm_bwd5_kernel)
+      }
+    }
+    DBG_STAMP(4);  // MFMA + publication
+    if (gw) {
+      for (int i = 0; i < my_pause; ++i) __builtin_amdgcn_s_sleep(1);
+      issue_gather(s + 1);
+    }
+    st_dg = __builtin_bit_cast(i32x4, dg4);
+    if constexpr (CELL == 1) st_dgh = __builtin_bit_cast(i32x4, dgh4);
+    st_goff = g_off;
+    st_t = t;
+    if constexpr (CELL != 1) {
+      st_rm = 0u;
+      if (p.rowmax && tid < NBR && tid < p.Bg && b0 + tid < B) st_rm = rowexp[par * 16 + tid];   // (rewritten two steps later)
+    }
+    g_off += g_step;
+    c_off += c_step;
+    y_off += y_step;
+    DBG_STAMP(5);  // gather issue + prefetch + stash
+    return true;
+  };
+  for (int s = 0; s < T; s += 2) {
+    if (!step(s, stA)) return false;
+    if (s + 1 < T) {
+      if (!step(s + 1, stB)) return false;
+    }
+  }
+  flush_stash();
+  return true;
+  };
+  const bool okrun = local ? run(std::true_type{}) : run(std::false_type{});
+  if (!okrun) return;
+  if (owner) {
+    const long row = (long)gid * NBR + brow;
+    *reinterpret_cast<f32x4*>(p.dbp + row * 4 * H + 4 * oj) = db_acc;
+    if constexpr (CELL == 1) *reinterpret_cast<f32x4*>(p.dbhp + row * 4 * H + 4 * oj) = dbh_acc;
+    if (p.colmax) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned a = __float_as_uint(cmx[e]);
+        if (a != 0u) atomicMax(p.colmax + (long)d * 4 * H + 4 * oj + e, a);
+        if constexpr (CELL == 1) {
+          const unsigned b = __float_as_uint(cmxh[e]);
+          if (b != 0u) atomicMax(p.colmax_h + (long)d * 4 * H + 4 * oj + e, b);
+        }
+      }
+    }
+  }
+  if (p.dbg && tid == 0) {
+    for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 8 + i] = dsum[i];
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    p.dbg[blockIdx.x * 8 + 6] = local ? 1 : 0;
+    p.dbg[blockIdx.x * 8 + 7] = xcc_id & 0xf;
+  }
+}
+
 }  // namespace
 
 // host side ----------------------------------------------------------------------------------------------------
@@ -712,7 +1141,21 @@ bool lstm5_supported(int T, int B, int H, int D, int cell) {
   return ((H % 128 == 0 && H >= 128 && H <= 512) || h640 || wide) && cell != RNNT_CELL_RNN_RELU;
 }
 
-int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
+static int env_pause(const char* name) {   // "e" or "e,l"
+  const char* v = getenv(name);
+  if (!v) return -1;
+  int e = atoi(v), l = e;
+  if (const char* c = strchr(v, ',')) l = atoi(c + 1);
+  return (e & 255) | ((l & 255) << 8);
+}
+
+int lstm5_fwd_launch(const LstmK& k_in, const Plan2& pl, int cell, hipStream_t s) {
+  LstmK k = k_in;
+  // A pause between a step's publication and its first poll round: the round issued right behind the publication never finds the
+  // operands (they are one L2 hand-off away) and its requests queue in front of the round that would.  Measured (paired bench runs,
+  // profiles/r02_poll_pause_ab.txt): 8-row groups at H = 512 (c2) 6.30 -> 6.10 ms of forward recurrences per step with 8 x 64 cycles,
+  // H = 640 (c5) 17.8 -> 17.4 with 6; 4-row groups (c3) lose 3 % with any pause.
+  { const int e = env_pause("RNNT_LSTM_FWD_PAUSE"); k.pause = e >= 0 ? e : (pl.Bg >= 8 ? (k.H == 640 ? 6 : 8) : 0); }
   const int nks = k.Kp / 128;
   int rc = RNNT_ERR_UNSUPPORTED;
   if (pl.MB == 5) {   // H = 640
@@ -757,7 +1200,10 @@ int lstm5_fwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
   return rc;
 }
 
-int lstm5_bwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
+int lstm5_bwd_launch(const LstmK& k_in, const Plan2& pl, int cell, hipStream_t s) {
+  LstmK k = k_in;
+  // (one-barrier form only) c2: 7.83 -> 7.55 ms of backward recurrences per step with 8 x 64 cycles, c3 13.4 -> 13.1; 12 and more lose again
+  { const int e = env_pause("RNNT_LSTM_BWD_PAUSE"); k.pause = e >= 0 ? e : (8 | (8 << 8)); }
   const int nks = k.Kp / 128;
   int rc = RNNT_ERR_UNSUPPORTED;
 #define B5Q(NM, C, ...)                                                                               \
@@ -797,6 +1243,38 @@ int lstm5_bwd_launch(const LstmK& k, const Plan2& pl, int cell, hipStream_t s) {
     if (cell == RNNT_CELL_LSTM) B5Q(4, 0, 8, 4, 32);
     else if (cell == RNNT_CELL_GRU) B5Q(4, 1, 8, 4, 32);
     else B5Q(4, 2, 8, 4, 32);
+    return rc;
+  }
+  if (!getenv("RNNT_LSTM_BWD5_2B")) {   // one-barrier form (default); RNNT_LSTM_BWD5_2B=1: lstm_bwd5_kernel (A/B partner)
+    const int threads = 256;
+    const size_t lds = (size_t)2 * 2 * 16 * (32 * 2 + 8) * 2 + 32 * 4 + 32 + 16;
+#define B5F(NM)                                                                                                   \
+    do {                                                                                                          \
+      if (cell == RNNT_CELL_LSTM) { if (pl.BQ == 1) rc = launch_persistent2(lstm_bwd5f_kernel<NM, 1, 0>, k, pl, lds, s, "lstm_bwd5f", threads);       \
+        else if (pl.BQ == 2) rc = launch_persistent2(lstm_bwd5f_kernel<NM, 2, 0>, k, pl, lds, s, "lstm_bwd5f", threads);                             \
+        else rc = launch_persistent2(lstm_bwd5f_kernel<NM, 4, 0>, k, pl, lds, s, "lstm_bwd5f", threads); }                                             \
+      else if (cell == RNNT_CELL_GRU) { if (pl.BQ == 1) rc = launch_persistent2(lstm_bwd5f_kernel<NM, 1, 1>, k, pl, lds, s, "lstm_bwd5f", threads);  \
+        else if (pl.BQ == 2) rc = launch_persistent2(lstm_bwd5f_kernel<NM, 2, 1>, k, pl, lds, s, "lstm_bwd5f", threads);                             \
+        else rc = launch_persistent2(lstm_bwd5f_kernel<NM, 4, 1>, k, pl, lds, s, "lstm_bwd5f", threads); }                                             \
+      else { if (pl.BQ == 1) rc = launch_persistent2(lstm_bwd5f_kernel<NM, 1, 2>, k, pl, lds, s, "lstm_bwd5f", threads);                             \
+        else if (pl.BQ == 2) rc = launch_persistent2(lstm_bwd5f_kernel<NM, 2, 2>, k, pl, lds, s, "lstm_bwd5f", threads);                             \
+        else rc = launch_persistent2(lstm_bwd5f_kernel<NM, 4, 2>, k, pl, lds, s, "lstm_bwd5f", threads); }                                             \
+    } while (0)
+    if (nks == 4 && !getenv("RNNT_LSTM_BWD5F_4W")) {   // H = 512: 8 waves x 4 output blocks (two waves per SIMD keep the MFMA pipe busy; one wave issues a
+      const int threads8 = 512;                         // v_mfma_f32_16x16x32_f16 only every 20-25 cycles), waves 4..7 share the MFMA + publication phase only
+#define B5F8(BQV, C) rc = launch_persistent2(lstm_bwd5f_kernel<4, BQV, C, 8>, k, pl, lds, s, "lstm_bwd5f", threads8)
+      if (cell == RNNT_CELL_LSTM) { if (pl.BQ == 1) B5F8(1, 0); else if (pl.BQ == 2) B5F8(2, 0); else B5F8(4, 0); }
+      else if (cell == RNNT_CELL_GRU) { if (pl.BQ == 1) B5F8(1, 1); else if (pl.BQ == 2) B5F8(2, 1); else B5F8(4, 1); }
+      else { if (pl.BQ == 1) B5F8(1, 2); else if (pl.BQ == 2) B5F8(2, 2); else B5F8(4, 2); }
+#undef B5F8
+      return rc;
+    }
+    if (nks == 1) B5F(2);
+    else if (nks == 2) B5F(4);
+    else if (nks == 3) B5F(6);
+    else if (nks == 4) B5F(8);
+    else set_error("lstm_bwd5: H = %d not supported", k.H);
+#undef B5F
     return rc;
   }
   const int threads = 256;

@@ -6,7 +6,7 @@ OUT=gpurun_out/ab_env.txt
 mkdir -p gpurun_out; : > $OUT
 for r in $(seq $ROUNDS); do
   for v in none $VARS; do
-    if [ $v = none ]; then E=; else E=$v; fi
+    if [ $v = none ]; then E=; else E=${v//+/ }; fi   # "A=1+B=2": several variables in one variant
     env $E timeout -k 10 300 python bench.py --config $CFG --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/ab_tmp.log 2>&1 || { tail -5 gpurun_out/ab_tmp.log; exit 1; }
     python - "$v" >> $OUT <<'P'
 import json,sys
