@@ -288,8 +288,10 @@ def main():
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None}
         if dom.startswith("lstm_"):
-            steps_per_launch = T
-            roof["note"] = (f"persistent recurrence: {T} dependent timesteps per launch, {1e6 * per_launch_s / steps_per_launch:.2f} us per "
+            # the kind's launches: one per encoder layer (T dependent timesteps) and one per prediction-net layer (U + 1)
+            timesteps = a.steps * (cfg[4][1] * T + cfg[5][1] * (U + 1))
+            roof["note"] = (f"persistent recurrence: {cfg[4][1]} launches of {T} dependent timesteps + {cfg[5][1]} of {U + 1} per step, "
+                            f"{1e3 * kd['ms_total'] / timesteps:.2f} us per "
                             "timestep; bounded by the per-step exchange (one L2 hand-off) + 48 MFMAs + cell math chain, not by HBM: "
                             "algorithmic bytes/launch = gates r+w, c, y or dy per (t,b,d) + weights (DESIGN.md section 4)")
     # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as

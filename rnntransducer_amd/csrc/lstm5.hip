@@ -653,6 +653,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
       }
     }
     DBG_STAMP(4);  // scale + MFMA + publication
+    for (int i = 0; i < (p.pause & 255); ++i) __builtin_amdgcn_s_sleep(1);
     issue_gather(s + 1);
     st_dg = __builtin_bit_cast(i32x4, dg4);
     if constexpr (CELL == 1) st_dgh = __builtin_bit_cast(i32x4, dgh4);
@@ -938,6 +939,8 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5f_kernel(const LstmK p) {
       const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;
       if (!__all(tags_ok(want))) ok = poll_tagged([&]() -> bool { issue_gather(s); return tags_ok(want); }, p.status);
       DBG_STAMP(1);
+      // (Tried: the next step's stash loads right here, one step ahead into the other register set — as far ahead of the next gather as a
+      //  load can be issued — instead of two steps ahead from inside the MFMA phase: c2 equal, c3 13.1 -> 14.0 ms.)
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         u32x4 v = gr[i];
@@ -1202,8 +1205,9 @@ int lstm5_fwd_launch(const LstmK& k_in, const Plan2& pl, int cell, hipStream_t s
 
 int lstm5_bwd_launch(const LstmK& k_in, const Plan2& pl, int cell, hipStream_t s) {
   LstmK k = k_in;
-  // (one-barrier form only) c2: 7.83 -> 7.55 ms of backward recurrences per step with 8 x 64 cycles, c3 13.4 -> 13.1; 12 and more lose again
-  { const int e = env_pause("RNNT_LSTM_BWD_PAUSE"); k.pause = e >= 0 ? e : (8 | (8 << 8)); }
+  // one-barrier form: c2 7.83 -> 7.55 ms of backward recurrences per step with 8 x 64 cycles, c3 13.4 -> 13.1; 12 and more lose again
+  const int env_p = env_pause("RNNT_LSTM_BWD_PAUSE");
+  k.pause = env_p >= 0 ? env_p : 0;   // lstm_bwd5_kernel (H = 640 at c5): any pause loses (22.3 -> 22.6 ms with 4, 24.0 with 12)
   const int nks = k.Kp / 128;
   int rc = RNNT_ERR_UNSUPPORTED;
 #define B5Q(NM, C, ...)                                                                               \
@@ -1246,6 +1250,7 @@ int lstm5_bwd_launch(const LstmK& k_in, const Plan2& pl, int cell, hipStream_t s
     return rc;
   }
   if (!getenv("RNNT_LSTM_BWD5_2B")) {   // one-barrier form (default); RNNT_LSTM_BWD5_2B=1: lstm_bwd5_kernel (A/B partner)
+    if (env_p < 0) k.pause = 8 | (8 << 8);
     const int threads = 256;
     const size_t lds = (size_t)2 * 2 * 16 * (32 * 2 + 8) * 2 + 32 * 4 + 32 + 16;
 #define B5F(NM)                                                                                                   \

@@ -12,8 +12,8 @@ import sys
 KINDS = (("gemm_hp_kernel", ("gemm_hp_kernel", "gemm_hp3_kernel")),
          ("gemm_bf16s_kernel", ("gemm_bf16s_kernel", "gemm_bf16s256_kernel")), ("gemm_f32_kernel", ("gemm_f32_kernel",)),
          ("lstm_fwd_kernel", ("lstm_fwd5_kernel", "lstm_fwd3_kernel", "lstm_fwd2_kernel", "lstm_fwd_kernel")),
-         ("lstm_bwd_kernel", ("lstm_bwd5_kernel", "lstm_bwd4_kernel", "lstm_bwd2_kernel", "lstm_bwd_kernel")),
-         ("hp_split_kernels", ("hp_split_kernel", "hp_split_t_kernel", "hp_colmax_kernel")),
+         ("lstm_bwd_kernel", ("lstm_bwd5f_kernel", "lstm_bwd5_kernel", "lstm_bwd4_kernel", "lstm_bwd2_kernel", "lstm_bwd_kernel")),
+         ("hp_split_kernels", ("hp_split_kernel", "hp_split_t_kernel", "hp_split_both_kernel", "hp_colmax_kernel")),
          ("lse_kernel", ("lse_sep_kernel", "lse_dense_kernel")), ("alphabeta_kernel", ("alphabeta_kernel",)),
          ("lattice_grad_kernel", ("grad_sep_kernel", "grad_dense_kernel", "reduce_dc_kernel")))
 HELPERS = ("reduce_dc", "hp_colmax")  # helper launches: their bytes count towards the kind, their launches do not
