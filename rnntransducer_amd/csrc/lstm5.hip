@@ -210,19 +210,24 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
       }
     return !inrow || (bad & TAG_MASK) == 0u;
   };
-  f32x4 xp = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_off, 0, 0));
+  // gate pre-activations (W_ih x + b, written by the input-projection GEMM).  H = 640 form: fetched TWO steps ahead into one of three
+  // register sets (loop body instantiated three times, so no register is moved while its load is in flight): c5 17.9 -> 17.4 ms of
+  // forward recurrences per step.  Other forms: one step ahead (two steps ahead measured 6.39 vs 6.22 ms at c2, equal at c3).
+  constexpr int AHEAD = MB == 5 ? 2 : 1;
+  f32x4 xpA = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_off, 0, 0));
+  f32x4 xpB = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, AHEAD == 2 && T > 1 ? g_off + g_step : OOB, 0, 0));
+  f32x4 xpC = {0.f, 0.f, 0.f, 0.f};
   // the previous step's stash, kept in registers until this step's operands have arrived: between a publication and the arrival
   // of the next operands the CU's memory queue holds the operand loads only
   i32x4 st_g = {0, 0, 0, 0};
   int st_c = 0, st_y = 0, st_yd = 0, st_goff = OOB, st_coff = OOB, st_yoff = OOB;
-  f32x4 xp_next = {0.f, 0.f, 0.f, 0.f};
   auto flush_stash = [&]() {
     __builtin_amdgcn_raw_buffer_store_b128(st_g, g_rsrc, st_goff, 0, 0);
     if constexpr (CELL == 0) __builtin_amdgcn_raw_buffer_store_b32(st_c, c_rsrc, st_coff, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(st_y, y_rsrc, st_yoff, 0, 0);
     if (p.ydrop) __builtin_amdgcn_raw_buffer_store_b32(st_yd, yd_rsrc, st_yoff, 0, 0);
   };
-  for (int s = 0; s < T; ++s) {
+  auto step = [&](const int s, const f32x4& xp, f32x4& xp_ld) -> bool {
     const int t = (d == 0) ? s : T - 1 - s;
     f32x4 acc[MB];
 #pragma unroll
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
     }
     // the previous step's stash and the next step's gate pre-activations: issued BEHIND this step's MFMAs (they execute while these
     // instructions issue; in front of them — or between the two k-steps' MFMAs — the same five VMEM issues cost 760 cycles per step)
-    xp_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + 1 < T ? g_off + g_step : OOB, 0, 0));
+    xp_ld = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, s + AHEAD < T ? g_off + AHEAD * g_step : OOB, 0, 0));
     flush_stash();
     if (!ok) *abort_lds = 1;   // benign race: any wave that gave up makes the whole workgroup leave after the barrier
     f32x4* pp = part + (s & 1) * (NWV * MB * 64);
@@ -331,8 +336,20 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
     g_off += g_step;
     c_off += c_step;
     y_off += y_step;
-    xp = xp_next;
     DBG_STAMP(5);
+    return true;
+  };
+  if constexpr (AHEAD == 2) {
+    for (int s = 0; s < T; s += 3) {
+      if (!step(s, xpA, xpC)) return false;
+      if (s + 1 < T && !step(s + 1, xpB, xpA)) return false;
+      if (s + 2 < T && !step(s + 2, xpC, xpB)) return false;
+    }
+  } else {
+    for (int s = 0; s < T; ++s) {
+      if (!step(s, xpA, xpB)) return false;
+      xpA = xpB;   // (one register after coalescing: the load is issued behind the last use of xpA)
+    }
   }
   flush_stash();
   return true;
