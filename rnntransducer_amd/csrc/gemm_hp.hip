@@ -237,6 +237,7 @@ struct HpGemmK {
   int splits, kt_per_split;  // blockIdx.y = split z handles K-tiles [z * kt_per_split, ...)
   float* slab;               // splits > 1: slab[z][M][N]
   int tiles_m, tiles_n;
+  int group_m;               // > 0: tiles walked in bands of group_m tile rows (see hp_grouped_tile); 0: plain column-major order
 };
 
 // same bijective XCD remap idea as gemm.hip: consecutive tiles of one XCD share operand panels through its L2
@@ -372,9 +373,24 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
   }
 }
 
+// Walk order of an XCD's contiguous share of the tiles.  Column-major order puts 32 tiles of ONE tile column in flight on an XCD:
+// 32 A panels + 1 B panel pass through its L2 for 32 tiles, and A is fetched tiles_n times over the launch (PMC: 1.4 GB read per
+// c2 launch against 0.15-0.55 GB of operands).  In bands of group_m tile rows (m fastest inside a band, then n) the 32 tiles in
+// flight are group_m x 32/group_m: 8 + 4 panels instead of 33.  Bijective on [0, tiles_m * tiles_n); returns the column-major index.
+__device__ __forceinline__ int hp_grouped_tile(int idx, int tiles_m, int tiles_n, int group_m) {
+  const int band = group_m * tiles_n;
+  const int g = idx / band, r = idx - g * band;
+  const int m_first = g * group_m;
+  const int gm = min(tiles_m - m_first, group_m);
+  const int n = r / gm, m = m_first + (r - n * gm);
+  return n * tiles_m + m;
+}
+
 __global__ void __launch_bounds__(512, 1) gemm_hp_kernel(const HpGemmK p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  hp_tile256(p, hp_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), blockIdx.y, lds);
+  int bid = hp_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  if (p.group_m > 0) bid = hp_grouped_tile(bid, p.tiles_m, p.tiles_n, p.group_m);
+  hp_tile256(p, bid, blockIdx.y, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -643,6 +659,11 @@ int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t
   const bool k3 = getenv("RNNT_GEMM_HP_3STAGE") != nullptr;   // opt-in: 256x128 tiles / 3-stage LDS ring (measured 10-14 % slower than 256x256 / 2 stages)
   k.tiles_m = (int)ceil_div(M, HP_BM); k.tiles_n = (int)ceil_div(N, k3 ? HP3_BN : HP_BN);
   const int tiles = k.tiles_m * k.tiles_n;
+  {  // band height of the tile walk: 8 x 4 tiles in flight per XCD when an XCD's share is >= 32 tiles, 4 x 2 for the small outputs
+    static const int env_gm = getenv("RNNT_GEMM_HP_GROUP_M") ? atoi(getenv("RNNT_GEMM_HP_GROUP_M")) : -1;
+    k.group_m = env_gm >= 0 ? env_gm : (tiles >= 256 ? 8 : 4);
+    if (k3) k.group_m = 0;
+  }
   int splits = 1;
   if (workspace && tiles < 192 && k.nkt >= 64) {  // too few tiles for 256 CUs and a deep contraction (weight gradients): split K
     long want = ceil_div(256, tiles);
