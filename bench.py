@@ -85,6 +85,11 @@ def host_cpu_info():
     return cores, model
 
 
+def progress(msg):
+    """Heartbeat on stderr (stdout carries exactly one JSON line): the CPU legs of the larger configs run for minutes."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def _oracle_for(model, tn, pn, V, double):
     from oracle.rnnt_oracle import OracleJointNet
     oracle = OracleJointNet(dict(tn, dropout=0.0), dict(pn, pad_token_id=0, dropout=0.0), V)
@@ -113,6 +118,7 @@ def cpu_baseline(model, tn, pn, V, batch, sample_b, threads, timed_steps=3):
         loss.backward()
         opt.step()
         times.append(time.perf_counter() - t0)
+        progress(f"cpu_baseline step {len(times)}/{1 + timed_steps}: {times[-1]:.1f} s")
     timed = sorted(times[1:])
     med = timed[len(timed) // 2]
     return sample_b / med, med, times
@@ -139,6 +145,7 @@ def parity_vs_float64_oracle(model, tn, pn, V, batch, nb, threads):
     ref = training_loss(oracle, (cpu_sub[0].double(),) + cpu_sub[1:])
     ref.backward()
     ref_loss = float(ref.detach())
+    progress(f"parity: float64 oracle done (loss {ref_loss:.6f}, HIP {hip_loss:.6f})")
     ref_grads = {k: p.grad for k, p in oracle.named_parameters() if k in GRAD_PROBES}
     # the same sample through the fp32 oracle (torch-CPU fp32 = the REFERENCE's own arithmetic): how far plain fp32 sits
     # from float64 on these gradients is the yardstick for the HIP path's distance (sums with heavy cancellation:
@@ -146,6 +153,7 @@ def parity_vs_float64_oracle(model, tn, pn, V, batch, nb, threads):
     o32 = _oracle_for(model, tn, pn, V, double=False)
     l32 = training_loss(o32, cpu_sub)
     l32.backward()
+    progress("parity: fp32 oracle done")
     f32_grads = {k: p.grad.double() for k, p in o32.named_parameters() if k in GRAD_PROBES}
     devs = {}
     for k in GRAD_PROBES:
@@ -329,6 +337,8 @@ def main():
                      "stash_note": "peak is dominated by the LSTM stash (activated gates, 16*H bytes per frame per direction per layer)"}
 
     parity_ok = True
+    if rank == 0:
+        progress(f"timed region done: {out['value']} utt/s, {out['ms_per_step']} ms per step")
     if world == 1 and not a.no_cpu_baseline:
         cores, cpu_model = host_cpu_info()
         threads = a.cpu_threads or cores

@@ -190,7 +190,8 @@ def test_gemm_split_pieces_are_exact_on_hard_values(gemm_mode_env):
 # ------------------------------------------------------------------------------------------------------------------
 # half-pair (hp) operands + the f16-MFMA GEMM (csrc/gemm_hp.hip)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (300, 257, 45), (1000, 520, 1024), (512, 256, 4096), (33, 700, 96), (1, 1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (300, 257, 45), (1000, 520, 1024), (512, 256, 4096), (33, 700, 96), (1, 1, 1),
+                                   (1400, 700, 64), (5381, 3328, 40)])  # 6 x 3 tiles (bands of 4, tail of 2), 22 x 13 tiles (bands of 8, tail of 6)
 def test_gemm_hp_matches_fp64(M, N, K):
     """C = A . B^T on hp operands against an fp64 product of the same fp32 inputs, wide dynamic range (rows of A over six
     decades): error relative to sum |a||b| no worse than the exact fp32 fma chain's bound; ragged edges in M, N and K."""
