@@ -329,37 +329,10 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
           acc[4 * mq + i][2 * nq + j] = c;
         }
     };
-#ifdef HP_B_RESIDENT   // A/B variant: all 4 B blocks of the wave stay in registers for the K-tile (24 instead of 28 ds_read_b128)
-    f16x8 b2[2][2];
-    auto load_b2 = [&]() {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        b2[j][0] = *reinterpret_cast<const f16x8*>(sb + (b_base + (2 + j) * 2048));
-        b2[j][1] = *reinterpret_cast<const f16x8*>(sb + ((b_base ^ 64) + (2 + j) * 2048));
-      }
-    };
-    auto mma2 = [&](int mq) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x4 c = acc[4 * mq + i][2 + j];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], b2[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b2[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b2[j][0], c, 0, 0, 0);
-          acc[4 * mq + i][2 + j] = c;
-        }
-    };
-    load_a(0); load_b(0); mma(0, 0);
-    load_b2(); mma2(0);
-    load_a(1); mma2(1);
-    mma(1, 0);
-#else
     load_a(0); load_b(0); mma(0, 0);
     load_b(1); mma(0, 1);
     load_a(1); mma(1, 1);
     load_b(0); mma(1, 0);
-#endif
     __builtin_amdgcn_sched_barrier(0);  // keep all 96 MFMAs in front of the wait (hipcc otherwise sinks half of them behind the barrier)
     __syncthreads();   // drains the LDS-DMA of the next stage (vmcnt(0)) and fences this stage's reads
   }
