@@ -24,6 +24,7 @@ def test_bench_emits_one_contract_line_with_roofline_and_cpu_baseline():
     assert j["dtype"] == "f32" and j["vs_baseline"] is None and j["value"] > 0
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
     assert abs(j["roofline"]["frac"] - j["roofline"]["achieved"] / j["roofline"]["peak"]) < 1e-3
+    assert j["roofline"]["launches"] > 0 and j["roofline"]["profiled_steps"].startswith("1 of the 3 timed steps")
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 4 and j["cpu_baseline"]["value"] > 0
     assert j["loss_rel_delta"] < 1e-4          # north_star tolerance on the whole path (mel, label) -> loss
     assert "workload" in j["config"] and "model" not in j["config"]
