@@ -221,7 +221,14 @@ class LinearFn(torch.autograd.Function):
                              f"bias {None if bias is None else tuple(bias.shape)}")
         M = x.numel() // K
         y = torch.empty(*lead, N, device=x.device, dtype=torch.float32)
-        gemm(M, N, K, x, W0, y, bias=bias)
+        # big products (the encoder's out_proj: 32000 x 512 x 1024 at config 2) take the half-pair f16 path of the LSTM layers'
+        # products (include/rnnt_hip.h: same fp32-grade arithmetic, 440 instead of 140-150 TFLOP/s); its operand splits only pay
+        # for themselves on deep, wide shapes
+        ctx.hp = M >= 1024 and N >= 256 and K >= 1024 and not os.environ.get("RNNT_GEMM_NO_HP")
+        if ctx.hp:
+            gemm_hp(hp_split(x.view(M, K)), hp_split(W0), out=y.view(M, N), bias=bias)
+        else:
+            gemm(M, N, K, x, W0, y, bias=bias)
         ctx.save_for_backward(x, W0)
         ctx.has_bias = bias is not None
         ctx.w_param, ctx.b_param = W, bias  # the Parameter objects themselves (for their flat .grad views)
@@ -236,12 +243,19 @@ class LinearFn(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(M, K, N, dy, W, dx, b_sn=1, b_sk=K)          # dx = dy . W
+            if ctx.hp:
+                gemm_hp(hp_split(dy.view(M, N)), hp_split(W, transpose=True), out=dx.view(M, K))   # dx = dy . W
+            else:
+                gemm(M, K, N, dy, W, dx, b_sn=1, b_sk=K)          # dx = dy . W
         if ctx.needs_input_grad[1]:
             tgt = _direct_grad(ctx.w_param)
             dW = torch.empty_like(W) if tgt is None else None
-            gemm(N, K, M, dy, x, dW if tgt is None else tgt, a_mc=True, a_sk=N, b_sn=1, b_sk=K, split_k=True,
-                 flags=0 if tgt is None else GEMM_ACCUM)  # dW = dy^T . x
+            if ctx.hp:   # dW = dy^T . x: both operands row-major over the contraction index M (transposed splits), split-K slabs
+                gemm_hp(hp_split(dy.view(M, N), transpose=True), hp_split(x.view(M, K), transpose=True),
+                        out=dW if tgt is None else tgt, accumulate=tgt is not None)
+            else:
+                gemm(N, K, M, dy, x, dW if tgt is None else tgt, a_mc=True, a_sk=N, b_sn=1, b_sk=K, split_k=True,
+                     flags=0 if tgt is None else GEMM_ACCUM)  # dW = dy^T . x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N, into=_direct_grad(ctx.b_param))
         return dx, dW, db

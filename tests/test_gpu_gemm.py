@@ -310,3 +310,33 @@ def test_hp_split_both_orientations_in_one_pass_is_bitwise_two_splits(M, C):
     n_rm, n_tr = _lib.lib().rnnt_hip_hp_bytes(M, C), _lib.lib().rnnt_hip_hp_bytes(C, M)
     assert torch.equal(rm2.planes[:n_rm], rm.planes[:n_rm])
     assert torch.equal(tr2.planes[:n_tr], tr.planes[:n_tr])
+
+
+@pytest.mark.parametrize("hp", [True, False])
+def test_linear_big_products_on_the_half_pair_path_match_fp64(hp, monkeypatch):
+    """nn.Linear forward / backward (networks/encoder.py:76,103) at a shape LinearFn routes through the half-pair GEMM
+    (M >= 1024, N >= 256, K >= 1024) and, with RNNT_GEMM_NO_HP, through gemm.hip: y, dx, dW, db against an fp64 product of the
+    same fp32 values, error relative to sum |a||b| per element (the bound the hp GEMM tests use)."""
+    from rnntransducer_amd.ops import LinearFn
+    if not hp:
+        monkeypatch.setenv("RNNT_GEMM_NO_HP", "1")
+    g = torch.Generator().manual_seed(5)
+    T, B, K, N = 70, 32, 1024, 320
+    x = (torch.randn(T, B, K, generator=g) * torch.exp(torch.empty(T, B, 1).uniform_(-6, 2, generator=g))).requires_grad_()
+    W = (torch.randn(N, K, generator=g) * 0.05).requires_grad_()
+    b = torch.randn(N, generator=g).requires_grad_()
+    dy = torch.randn(T, B, N, generator=g) * torch.exp(torch.empty(T, B, 1).uniform_(-8, 0, generator=g))
+    xd, Wd, bd = (t.detach().double().requires_grad_() for t in (x, W, b))
+    yd = xd @ Wd.T + bd
+    yd.backward(dy.double())
+    xc, Wc, bc = (t.detach().cuda().requires_grad_() for t in (x, W, b))
+    y = LinearFn.apply(xc, Wc, bc)
+    y.backward(dy.cuda())
+    x2, dy2 = x.detach().double().view(-1, K), dy.double().view(-1, N)
+    scales = {"y": x2.abs() @ Wd.detach().abs().T + bd.detach().abs(), "dx": dy2.abs() @ Wd.detach().abs(),
+              "dW": dy2.abs().T @ x2.abs(), "db": dy2.abs().sum(0)}
+    got = {"y": y.detach().view(-1, N), "dx": xc.grad.view(-1, K), "dW": Wc.grad, "db": bc.grad}
+    want = {"y": yd.detach().view(-1, N), "dx": xd.grad.view(-1, K), "dW": Wd.grad, "db": bd.grad}
+    for k in got:
+        err = ((got[k].double().cpu() - want[k]).abs() / (scales[k] + 1e-30)).max().item()
+        assert err < (2e-5 if k == "db" else 3e-6 if hp else 6e-6), (k, err)   # db: an fp32 column sum over 2240 rows
