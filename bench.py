@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — utterances/sec of the full RNN-T training step on the MI355X HIP hot path.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 without WORLD_SIZE in the environment the
+                                                              process is a LAUNCHER — before any GPU call it starts N ranks
+                                                              through torch.distributed.run on 127.0.0.1, forwards rank 0's
+                                                              JSON line and exits with the ranks' code; fewer than N visible
+                                                              devices is an error, never a silent 1-GPU run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W                (N>1, one rank per GPU, RCCL over xGMI)
+        bench.py --gpus N --steps K --warmup W                (N>1, one rank per GPU, RCCL over xGMI: what the launcher runs)
 
 A "step" = forward (LSTM encoder + LSTM prediction net) + fused joint/RNN-T loss + backward + flat-gradient
 all-reduce + AdamW, on one synthetic batch that is already resident in HBM.  Workload at every N: BASELINE.json
@@ -15,7 +19,13 @@ Rank 0 prints ONE JSON line with the driver's contract plus
                  library's opt-in profiler; algorithmic FLOPs/bytes per launch are computed in the launch wrappers),
   "cpu_baseline" the CPU oracle (torch-CPU composite of the reference path + C loss) timed on this box's host cores
                  on a bounded sample, N=1 only,
-  "loss_rel_delta" |L_hip - L_oracle| / L_oracle on that same sample (dropout off on both sides).
+  "loss_rel_delta" / "grad_max_abs_dev"  the HIP path against the FLOAT64 oracle at the INITIAL weights, measured BEFORE the
+                 timed steps on the launch geometry that is timed: the HIP side runs the FULL bench batch (B rows, the same sync
+                 groups / workgroup count as a timed step) with per-utterance losses, and back-propagates the mean over the first
+                 `--parity-sample` utterances only (the other rows get upstream weight 0; rows are independent), so loss and
+                 gradients are comparable with the oracle's run on those utterances.  Gate: loss 1e-4 relative, gradients 2e-4 of
+                 the tensor's maximum — the fixture tests' bound, no widening.  The same comparison on the weights the timed steps
+                 left is reported under "parity_after_training" (informational: conditioning, not a gate).
 """
 import argparse
 import ctypes
@@ -124,51 +134,138 @@ def cpu_baseline(model, tn, pn, V, batch, sample_b, threads, timed_steps=3):
     return sample_b / med, med, times
 
 
-def parity_vs_float64_oracle(model, tn, pn, V, batch, nb, threads):
-    """Loss + the three probe gradients (SURVEY §8d "Loss delta") of the HIP path on the CURRENT weights, dropout off,
-    against the float64 oracle on the first `nb` utterances of the bench batch."""
+def parity_vs_float64_oracle(model, opt, tn, pn, V, batch, nb, threads, with_fp32_oracle):
+    """Loss + the three probe gradients (SURVEY §8d "Loss delta") of the HIP path on the CURRENT weights, dropout off, against the
+    float64 oracle on the first `nb` utterances of the bench batch.  The HIP side runs the WHOLE bench batch — the launch that is
+    timed: same B, same sync groups, same workgroup count — with reduction "none" and back-propagates nll[:nb].mean(): rows >= nb
+    get upstream weight 0 and, rows being independent, contribute nothing to any gradient."""
     from oracle.rnnt_oracle import training_loss
     torch.set_num_threads(threads)
     was_training = model.training
     model.eval()
-    sub = tuple((x[:nb] if isinstance(x, torch.Tensor) else x[:nb]) for x in batch)
-    for p in model.parameters():
-        if p.grad is not None:
-            p.grad.zero_()
-    hip_l = model.jointnet.loss(sub[0], sub[2], sub[3], sub[5], sub[6], model.blank_token_id).mean()
+    opt.zero_grad()
+    nll = model.jointnet.loss(batch[0], batch[2], batch[3], batch[5], batch[6], model.blank_token_id, reduction="none")
+    hip_l = nll[:nb].mean()
     hip_l.backward()
     hip_loss = float(hip_l.detach())
+    hip_nll = nll.detach().double().cpu()
     hip_grads = {k: p.grad.detach().double().cpu().clone() for k, p in model.jointnet.named_parameters() if k in GRAD_PROBES}
+    opt.zero_grad()
     model.train(was_training)
     oracle = _oracle_for(model, tn, pn, V, double=True)
-    cpu_sub = tuple((x.cpu() if isinstance(x, torch.Tensor) else x) for x in sub)
+    cpu_sub = tuple((x[:nb].cpu() if isinstance(x, torch.Tensor) else x[:nb]) for x in batch)
     ref = training_loss(oracle, (cpu_sub[0].double(),) + cpu_sub[1:])
     ref.backward()
     ref_loss = float(ref.detach())
-    progress(f"parity: float64 oracle done (loss {ref_loss:.6f}, HIP {hip_loss:.6f})")
+    progress(f"parity: float64 oracle done (loss {ref_loss:.6f}, HIP {hip_loss:.6f}; HIP ran all {len(hip_nll)} rows)")
     ref_grads = {k: p.grad for k, p in oracle.named_parameters() if k in GRAD_PROBES}
-    # the same sample through the fp32 oracle (torch-CPU fp32 = the REFERENCE's own arithmetic): how far plain fp32 sits
-    # from float64 on these gradients is the yardstick for the HIP path's distance (sums with heavy cancellation:
-    # tools/parity_probe.py shows the distance does not move with exact cell math or f32-input MFMA)
-    o32 = _oracle_for(model, tn, pn, V, double=False)
-    l32 = training_loss(o32, cpu_sub)
-    l32.backward()
-    progress("parity: fp32 oracle done")
-    f32_grads = {k: p.grad.double() for k, p in o32.named_parameters() if k in GRAD_PROBES}
+    f32_grads, f32_loss_rel = None, None
+    if with_fp32_oracle:
+        # the same sample through the fp32 oracle (torch-CPU fp32 = the REFERENCE's own arithmetic): how far plain fp32 sits
+        # from float64 on these gradients — informational yardstick for the post-training comparison
+        o32 = _oracle_for(model, tn, pn, V, double=False)
+        l32 = training_loss(o32, cpu_sub)
+        l32.backward()
+        progress("parity: fp32 oracle done")
+        f32_grads = {k: p.grad.double() for k, p in o32.named_parameters() if k in GRAD_PROBES}
+        f32_loss_rel = abs(float(l32.detach()) - ref_loss) / abs(ref_loss)
     devs = {}
     for k in GRAD_PROBES:
         scale = float(ref_grads[k].abs().max())
-        devs[k] = {"max_abs_dev": float((hip_grads[k] - ref_grads[k]).abs().max()), "ref_max_abs": scale,
-                   "fp32_oracle_max_abs_dev": float((f32_grads[k] - ref_grads[k]).abs().max())}
+        devs[k] = {"max_abs_dev": float((hip_grads[k] - ref_grads[k]).abs().max()), "ref_max_abs": scale}
         devs[k]["rel_to_max"] = devs[k]["max_abs_dev"] / max(scale, 1e-30)
-        devs[k]["fp32_oracle_rel_to_max"] = devs[k]["fp32_oracle_max_abs_dev"] / max(scale, 1e-30)
-    return abs(hip_loss - ref_loss) / abs(ref_loss), devs, abs(float(l32.detach()) - ref_loss) / abs(ref_loss)
+        if f32_grads is not None:
+            devs[k]["fp32_oracle_max_abs_dev"] = float((f32_grads[k] - ref_grads[k]).abs().max())
+            devs[k]["fp32_oracle_rel_to_max"] = devs[k]["fp32_oracle_max_abs_dev"] / max(scale, 1e-30)
+    return abs(hip_loss - ref_loss) / abs(ref_loss), devs, f32_loss_rel, bool(torch.isfinite(hip_nll).all())
 
 
 def grad_within_tolerance(v):
-    """max_abs_dev <= 2e-4 * max(|ref|max, 1e-3) (the bound tests/test_gpu_model.py uses at initial weights), or — on
-    weights where plain fp32 itself is further than that from float64 — within 1.5x of the fp32 oracle's own deviation."""
-    return v["max_abs_dev"] <= max(2e-4 * max(v["ref_max_abs"], 1e-3), 1.5 * v["fp32_oracle_max_abs_dev"])
+    """max_abs_dev <= 2e-4 * max(|ref|max, 1e-3): the bound tests/test_gpu_model.py and tests/test_gpu_configs.py use."""
+    return v["max_abs_dev"] <= 2e-4 * max(v["ref_max_abs"], 1e-3)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` (N > 1) without a distributed environment: this process becomes the launcher.  It touches no GPU
+    (torch.cuda.device_count() does not initialise one), checks that N devices are visible, starts N ranks — one per GPU — through
+    `python -m torch.distributed.run` on 127.0.0.1 (what scripts/run_train.sh:7-9 of the reference does with torchrun), lets their
+    stdout / stderr through (rank 0 prints the JSON line) and exits with the ranks' return code."""
+    import subprocess
+    if not a.stub:
+        ndev = torch.cuda.device_count()
+        if ndev < a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) are visible; refusing to measure fewer devices than asked")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")              # scripts/run_train.sh:7
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    progress(f"launcher: starting {a.gpus} ranks: {' '.join(cmd[1:8])} ...")
+    rc = subprocess.call(cmd, env=env)
+    raise SystemExit(rc)
+
+
+def run_stub(a, rank, world):
+    """Launcher / sharding / timing plumbing on the CPU (tests only: `--stub`, gloo, no model, no kernel): everything the N > 1 path
+    of main() does AROUND the step — process group, the c4 ragged deal, the barrier-bracketed timed loop with the flat-gradient
+    all-reduce (the product's FlatParams on CPU tensors), the max-over-ranks reduction — with the step itself replaced by a sleep.
+    Prints a line that cannot be mistaken for a measurement (metric "stub")."""
+    from rnntransducer_amd.data import global_ragged_lengths, length_grouped_indices, synthetic_batch
+    from rnntransducer_amd.optim import FlatParams
+    if world > 1:
+        dist.init_process_group("gloo")
+    B, T, U, V = CONFIGS[a.config][:4]
+    t_lengths = None
+    if a.ragged:
+        glob = global_ragged_lengths(world * B, T)
+        t_lengths = [glob[i] for i in length_grouped_indices(glob, rank, world)]
+    batch = synthetic_batch(B, T, U, V, ragged=a.ragged, seed=1234 + rank, device="cpu", t_lengths=t_lengths)
+    torch.manual_seed(0)
+    flat = FlatParams(torch.nn.Linear(8, 8).parameters())
+    status = torch.zeros(4, dtype=torch.int32)
+
+    def step():
+        flat.zero_grad()
+        flat.flat_grad[:flat.n_param] += float(rank + 1)
+        time.sleep(0.002 * (rank + 1))
+        flat.all_reduce_grads(status)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    own_dt = dt
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    out = {"metric": "stub (launcher test only, nothing was measured)", "value": None, "unit": "utt/s", "n_gpus": world,
+           "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup, "data": "stub",
+           "ms_per_step": round(1e3 * dt / a.steps, 3), "own_ms_per_step": round(1e3 * own_dt / a.steps, 3),
+           "grad_sum_per_element": float(flat.flat_grad[0]), "status_slot": float(flat.status_slot()[0]),
+           "config": {"workload": f"stub {a.config}", "global_batch": world * B, "parallelism": f"dp{world}",
+                      "rank_t_lengths_head": batch[1][:4], "ragged": bool(a.ragged)}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -189,15 +286,27 @@ def main():
     ap.add_argument("--unprofiled-steps", type=int, default=0,
                     help="diagnostic: after the timed region, time this many more steps with the library's HIP-event profiler off "
                          "(reported as ms_per_step_unprofiled; never the headline value)")
+    ap.add_argument("--stub", action="store_true",
+                    help="tests only: run the launcher / sharding / timing plumbing on the CPU (gloo) with the step replaced by a "
+                         "sleep; prints metric 'stub', never a measurement")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a, sys.argv[1:])   # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the two must agree (start bench.py without a distributed "
+                         f"environment and it launches its own {a.gpus} ranks)")
+    if a.stub:
+        return run_stub(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists in rnntransducer_amd)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -237,6 +346,18 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # parity gate FIRST: initial weights, the full bench batch on the HIP side (the launch geometry that is timed), float64 oracle
+    # on the first --parity-sample utterances, strict tolerances (loss 1e-4 relative, gradients 2e-4 of the tensor's maximum)
+    parity = None
+    want_cpu_legs = world == 1 and not a.no_cpu_baseline
+    if want_cpu_legs:
+        cores, cpu_model = host_cpu_info()
+        threads = a.cpu_threads or cores
+        npar = min(a.parity_sample, B)
+        lrd, gdev, _, finite = parity_vs_float64_oracle(model, opt, tn, pn, V, batch, npar, threads, with_fp32_oracle=False)
+        parity = {"loss_rel_delta": lrd, "grad_max_abs_dev": gdev, "all_rows_finite": finite,
+                  "ok": bool(finite and lrd <= 1e-4 and all(grad_within_tolerance(v) for v in gdev.values()))}
 
     for _ in range(a.warmup):
         step()
@@ -321,10 +442,14 @@ def main():
     # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
     # MI355X_MICROARCH.md prescribes); collected offline because counters cannot be read from inside the process
     try:
+        from rnntransducer_amd.csrc.build import source_digest
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-        if pmc.get("config") == a.config:
+        # only numbers collected on THIS build of the kernels (the file is stamped with a digest of csrc/): stale ones are omitted
+        if pmc.get("config") == a.config and pmc.get("csrc_sha16") == source_digest():
             roof["traffic"] = round(pmc["hbm_bytes_per_launch"][dom])
             roof["traffic_source"] = pmc["from"]
+        elif pmc.get("config") == a.config:
+            roof["traffic_note"] = "profiles/pmc_traffic_latest.json was collected on another build of csrc/: omitted"
     except (OSError, KeyError, ValueError):
         pass
     roof["avg_launch_us"] = kd["avg_us"]
@@ -355,23 +480,26 @@ def main():
 
     if dt_unprof is not None:
         out["ms_per_step_unprofiled"] = round(1e3 * dt_unprof, 3)
+    out["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
     parity_ok = True
     if rank == 0:
         progress(f"timed region done: {out['value']} utt/s, {out['ms_per_step']} ms per step")
-    if world == 1 and not a.no_cpu_baseline:
-        cores, cpu_model = host_cpu_info()
-        threads = a.cpu_threads or cores
-        # (1) parity: HIP (dropout off, CURRENT weights — they moved during the timed steps) vs the FLOAT64 oracle
-        npar = min(a.parity_sample, B)
-        out["loss_rel_delta"], out["grad_max_abs_dev"], f32_loss_rel = parity_vs_float64_oracle(model, tn, pn, V, batch, npar, threads)
-        out["parity"] = {"oracle": f"float64 CPU oracle, first {npar} utterances of the bench batch, dropout off, weights after "
-                                   f"{a.warmup + a.steps} AdamW steps",
-                         "loss_rel_tol": 1e-4, "fp32_oracle_loss_rel_delta": f32_loss_rel,
-                         "grad_tol": "max_abs_dev <= max(2e-4 * max(ref_max_abs, 1e-3), 1.5 * fp32_oracle_max_abs_dev): within the "
-                                     "fixture tests' bound, or as close to float64 as the reference's own fp32 arithmetic (torch CPU)"}
-        parity_ok = out["loss_rel_delta"] <= 1e-4 and all(grad_within_tolerance(v) for v in out["grad_max_abs_dev"].values())
-        out["parity"]["ok"] = parity_ok
-        # (2) reported CPU baseline: fp32 oracle, 1 warm-up + 3 timed full train steps, median
+    if want_cpu_legs:
+        # (1) the parity gate measured before the timed steps (initial weights, full-batch HIP launch, float64 oracle)
+        out["loss_rel_delta"], out["grad_max_abs_dev"] = parity["loss_rel_delta"], parity["grad_max_abs_dev"]
+        parity_ok = parity["ok"]
+        out["parity"] = {"oracle": f"float64 CPU oracle on the first {npar} utterances of the bench batch, INITIAL weights, dropout off; the "
+                                   f"HIP side ran all {B} rows of the bench batch (the timed launch geometry) with upstream weight 0 on "
+                                   f"rows >= {npar}", "loss_rel_tol": 1e-4,
+                         "grad_tol": "max_abs_dev <= 2e-4 * max(ref_max_abs, 1e-3) (the fixture tests' bound)",
+                         "all_rows_finite": parity["all_rows_finite"], "ok": parity_ok}
+        # (2) informational: the same comparison on the weights the timed steps left, next to the fp32 oracle's own distance from
+        # float64 (sums with heavy cancellation: conditioning, tools/parity_probe.py) — reported, never a gate
+        lrd2, gdev2, f32_loss_rel, finite2 = parity_vs_float64_oracle(model, opt, tn, pn, V, batch, npar, threads, with_fp32_oracle=True)
+        out["parity_after_training"] = {"weights": f"after {a.warmup + a.steps} AdamW steps", "informational": True,
+                                        "loss_rel_delta": lrd2, "fp32_oracle_loss_rel_delta": f32_loss_rel,
+                                        "grad_max_abs_dev": gdev2, "all_rows_finite": finite2}
+        # (3) reported CPU baseline: fp32 oracle, 1 warm-up + 3 timed full train steps, median
         nb = min(a.cpu_sample, B)
         v, med, times = cpu_baseline(model, tn, pn, V, batch, nb, threads)
         out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": threads, "kind": "port",
@@ -381,11 +509,11 @@ def main():
                                          f"{med:.1f} s/step, torch.set_num_threads({threads})"}
         out["speedup_vs_cpu_baseline"] = round(out["value"] / v, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     if not parity_ok:
-        raise SystemExit("bench.py: parity leg outside tolerance (see loss_rel_delta / grad_max_abs_dev in the line above)")
+        raise SystemExit("bench.py: parity gate outside tolerance (see loss_rel_delta / grad_max_abs_dev in the line above)")
 
 
 if __name__ == "__main__":

@@ -138,6 +138,9 @@ int rnnt_hip_gemm_hp(const void* A, const uint32_t* a_amax, const void* B, const
  * (one launch tail instead of one per product).  xcd_skip: bit x set = workgroups that find themselves on XCD x leave at once, the
  * other XCDs do all the work — for products that run on a second stream beside a persistent recurrence (rnnt_lstm_bwd_desc.phase).
  * workspace: rnnt_hip_gemm_hp_grouped_workspace_bytes(...) bytes, 256-byte aligned (queue counters + deterministic split-K slabs).
+ * Self-check: a kernel behind the launch compares the units completed with the units queued; if they differ (xcd_skip named XCDs the
+ * device does not expose, so every workgroup left) it sets word 9 of `workspace` to 1 — callers of this entry that pass a non-zero
+ * xcd_skip read it back; rnnt_hip_lstm_bwd raises its sticky status word instead (and only passes a mask on a 256-CU device).
  * Used internally by rnnt_hip_lstm_bwd for dW_ih / dW_hh; exposed for tests. */
 typedef struct rnnt_hp_problem {
   const void* A; const uint32_t* a_amax;   /* (M x K) planes + row maxima */
@@ -229,7 +232,8 @@ typedef struct rnnt_lstm_bwd_desc {
                        * not reuse before phase 2 is done: alternate two workspaces). */
   int32_t beside_recurrence; /* phase 2 only, a hint: 1 = a recurrence of the same (B,H,D) runs concurrently on another stream; the
                        * big products then leave the XCDs that recurrence occupies alone (its workgroups exchange through their
-                       * XCD's L2) and run as one queue-driven launch on the others.  Results do not depend on it. */
+                       * XCD's L2) and run as one queue-driven launch on the others.  Results do not depend on it (honoured only on a
+                       * device that exposes all 8 XCDs; a launch that left work undone raises `f.status`). */
 } rnnt_lstm_bwd_desc;
 #define RNNT_LSTM_BWD_ALL 0
 #define RNNT_LSTM_BWD_RECUR 1

@@ -159,8 +159,27 @@ def rnnt_loss_mean(logits, targets, t_lens, u_lens, blank: int = 0) -> torch.Ten
 # ----------------------------------------------------------------------------------------------------
 # networks (networks/encoder.py, networks/decoder.py, networks/transducer.py) — torch-CPU composite
 # ----------------------------------------------------------------------------------------------------
+PER_UTTERANCE = False  # see _per_utterance_lstm; switched on by tests at config 3 / 5 sizes only
+
+
+def _per_utterance_lstm(rnn: nn.Module, x: torch.Tensor, lens: Sequence[int]) -> torch.Tensor:
+    """The same function as `_packed_lstm`, computed one utterance at a time on its own valid prefix (no PackedSequence): a packed
+    batch treats every sequence independently, ends it at its own length (the reverse direction starts at its own last frame) and
+    pads the output with zeros — exactly what running `rnn` on x[b, :len_b] alone and zero-padding gives.  Exists because autograd
+    through a PackedSequence on the CPU costs O(T^2) (every timestep's slice gradient is a full-size zero tensor): 114 s instead of
+    a few seconds for config 3's T = 2000.  Equality with `_packed_lstm` (1e-12, outputs and every gradient) is pinned by
+    tests/test_oracle_networks.py::test_per_utterance_lstm_equals_the_packed_one."""
+    outs = []
+    for b, n in enumerate(lens):
+        y, _ = rnn(x[b:b + 1, :int(n)])
+        outs.append(F.pad(y, (0, 0, 0, x.size(1) - int(n))))
+    return torch.cat(outs, dim=0)
+
+
 def _packed_lstm(rnn: nn.Module, x: torch.Tensor, lens: Sequence[int]) -> torch.Tensor:
     """encoder.py:93-102 / decoder.py:105-120: packed-sequence LSTM, zero outputs on padded frames."""
+    if PER_UTTERANCE and not (rnn.training and rnn.dropout > 0):
+        return _per_utterance_lstm(rnn, x, lens)
     total = x.size(1)
     packed = nn.utils.rnn.pack_padded_sequence(x, torch.as_tensor(list(lens), device="cpu"), batch_first=True,
                                                enforce_sorted=False)
@@ -223,8 +242,19 @@ class OracleJointNet(nn.Module):
         d = dec[:, None, :, :].expand(-1, T, -1, -1)
         return self.fc(F.gelu(torch.cat((e, d), dim=-1), approximate="tanh"))
 
-    def forward(self, audios, audio_lens, texts, text_lens):
-        return self.joint(self.encoder(audios, audio_lens), self.decoder(texts, text_lens))
+    def joint_separable(self, enc: torch.Tensor, dec: torch.Tensor) -> torch.Tensor:
+        """The same logits without the (B,T,U+1,2*O) concat: GELU is element-wise and fc is linear, so
+        fc(gelu(cat(e, d))) = gelu(e) W[:, :O_e]^T + gelu(d) W[:, O_e:]^T + b.  For float64 checks at sizes where the
+        concat does not fit (config 3 / 5: 8-10 GB per copy); equality with `joint` is pinned at small sizes by
+        tests/test_oracle_networks.py."""
+        Oe = enc.size(-1)
+        A = F.gelu(enc, approximate="tanh") @ self.fc.weight[:, :Oe].T
+        C = F.gelu(dec, approximate="tanh") @ self.fc.weight[:, Oe:].T
+        return A[:, :, None, :] + C[:, None, :, :] + self.fc.bias
+
+    def forward(self, audios, audio_lens, texts, text_lens, separable: bool = False):
+        enc, dec = self.encoder(audios, audio_lens), self.decoder(texts, text_lens)
+        return self.joint_separable(enc, dec) if separable else self.joint(enc, dec)
 
     @torch.no_grad()
     def recognize_greedy(self, audios, audio_lens, blank: int, max_iters: int = 3, return_margin: bool = False,
@@ -263,10 +293,11 @@ class OracleJointNet(nn.Module):
         return (out, margin) if return_margin else out
 
 
-def training_loss(net: OracleJointNet, batch, blank: int = 0) -> torch.Tensor:
-    """model.py:54-57 restated: unpack the 7-tuple, forward, mean RNN-T loss."""
+def training_loss(net: OracleJointNet, batch, blank: int = 0, separable: bool = False) -> torch.Tensor:
+    """model.py:54-57 restated: unpack the 7-tuple, forward, mean RNN-T loss.  `separable`: the concat-free form of the joint
+    (same logits; for float64 checks at config 3 / 5 sizes)."""
     audios, audio_lens, t_lens, texts, text_lens, targets, u_lens = batch
-    logits = net(audios, audio_lens, texts, text_lens)
+    logits = net(audios, audio_lens, texts, text_lens, separable=separable)
     return rnnt_loss_mean(logits, targets, t_lens, u_lens, blank)
 
 

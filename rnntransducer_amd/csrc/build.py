@@ -23,6 +23,17 @@ if os.environ.get("RNNT_BUILD_VGPR_FORM"):
     EXTRA_FLAGS = {"lstm5.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
+def source_digest() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources: stamps measurements that belong to ONE build (profiles/pmc_traffic_latest.json;
+    bench.py drops the stamped numbers when the sources have changed since)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + ["common.hpp", "lstm_shared.hpp"]):
+        with open(os.path.join(HERE, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -57,7 +57,9 @@ int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t
             int64_t c_div, int64_t c_so, int64_t c_si, const float* bias, unsigned flags, void* workspace, size_t workspace_bytes,
             hipStream_t s);
 // several NT products in ONE queue-driven launch (workgroups on the XCDs of `xcd_skip` leave at once): the weight-gradient
-// products that run beside the next layer's recurrence.  `counter`: 8 device words (one queue per XCD), zeroed here.
+// products that run beside the next layer's recurrence.  `counter`: 16 device words, zeroed here: [0..7] one queue per XCD, [8] units completed, [9] set to 1 by the check
+// kernel behind the launch when [8] != the number of units (a device that exposes fewer XCDs than `xcd_skip` assumes: every workgroup
+// left and nothing was computed) — and then `status` (optional sticky device word, the recurrences' rnnt_lstm_desc.status) is raised to 2.
 struct HpProblem {
   const void* A; const uint32_t* a_amax; const void* B; const uint32_t* b_amax;
   int64_t M, N, K;
@@ -67,7 +69,8 @@ struct HpProblem {
 constexpr int HP_GROUP_MAX = 4;
 size_t hp_gemm_grouped_workspace_bytes(const int64_t* MN, int n);   // MN[i] = M_i * N_i
 int hp_gemm_grouped(const HpProblem* pr, int n, unsigned xcd_skip, unsigned* counter, void* workspace, size_t workspace_bytes,
-                    hipStream_t s);
+                    hipStream_t s, unsigned* status = nullptr);
+constexpr size_t HPQ_HEADER_BYTES = 256;   // room for `counter` in front of the slabs when both come out of one workspace
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // gelu_tanh and its derivative (torch.nn.GELU(approximate="tanh"), networks/transducer.py:38)

@@ -407,7 +407,7 @@ struct HpGemmQ {
   int unit_end[HPQ_MAX];   // prefix sums of tiles * splits
   int nprob;
   unsigned xcd_skip;
-  unsigned* counter;       // 8 words (one queue per XCD), zeroed before the launch
+  unsigned* counter;       // 16 words, zeroed before the launch: [0..7] one queue per XCD, [8] units completed, [9] "incomplete" (hpq_check_kernel)
 };
 
 // Unit u of a problem: n-tile fastest, then K-split, then m-tile — neighbours in the queue share the A panel (same rows, same
@@ -441,7 +441,19 @@ __global__ void __launch_bounds__(512, 1) gemm_hpq_kernel(const HpGemmQ q) {
       const int local = u - (pi ? q.unit_end[pi - 1] : 0);
       const int tn = local % p.tiles_n, z = (local / p.tiles_n) % p.splits, tm = local / (p.tiles_n * p.splits);
       hp_tile256(p, tn * p.tiles_m + tm, z, lds);
+      if (threadIdx.x == 0) atomicAdd(q.counter + 8, 1u);   // read by hpq_check_kernel behind this launch
     }
+  }
+}
+
+// Self-check of the queue-driven launch: every unit must have been drawn by SOME workgroup.  With `xcd_skip` set that rests on the
+// device exposing the XCDs the mask leaves (a partitioned device, a CU-masked queue or another XCC numbering could make every
+// workgroup leave): then nothing was written, and instead of un-permuting stale slabs into the gradients with rc = 0 this raises
+// counter[9] and the caller's sticky status word (2), which the guarded AdamW update and FlatAdamW.step() act on.
+__global__ void hpq_check_kernel(unsigned* counter, unsigned total, unsigned* status) {
+  if (counter[8] != total) {
+    counter[9] = 1u;
+    if (status) __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -701,7 +713,7 @@ size_t hp_gemm_grouped_workspace_bytes(const int64_t* MN, int n) {
 }
 
 int hp_gemm_grouped(const HpProblem* pr, int n, unsigned xcd_skip, unsigned* counter, void* workspace, size_t workspace_bytes,
-                    hipStream_t s) {
+                    hipStream_t s, unsigned* status) {
   RNNT_CHECK_ARG(pr && n >= 1 && n <= HPQ_MAX && counter, "gemm_hp grouped: 1..%d problems and a counter word", HPQ_MAX);
   RNNT_CHECK_ARG((xcd_skip & 0xffu) != 0xffu, "gemm_hp grouped: xcd_skip leaves no XCD");
   HpGemmQ q = {};
@@ -748,7 +760,7 @@ int hp_gemm_grouped(const HpProblem* pr, int n, unsigned xcd_skip, unsigned* cou
     units += k.tiles_m * k.tiles_n * k.splits;
     q.unit_end[i] = units;
   }
-  RNNT_CHECK_HIP(hipMemsetAsync(counter, 0, 32, s));
+  RNNT_CHECK_HIP(hipMemsetAsync(counter, 0, 64, s));
   const int lds = 2 * HP_STAGE + 16;
   RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hpq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   {
@@ -756,6 +768,8 @@ int hp_gemm_grouped(const HpProblem* pr, int n, unsigned xcd_skip, unsigned* cou
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
     hipLaunchKernelGGL(gemm_hpq_kernel, dim3(!xcd_skip && units < cus ? units : cus), dim3(512), lds, s, q);   // with skipped XCDs: one per CU, an eighth lands on each XCD
+    RNNT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(hpq_check_kernel, dim3(1), dim3(1), 0, s, counter, (unsigned)units, status);
     RNNT_CHECK_LAUNCH();
     for (int i = 0; i < n; ++i)
       if (q.prob[i].splits > 1) {

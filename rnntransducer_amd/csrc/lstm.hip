@@ -1428,6 +1428,14 @@ struct LstmWs {
 inline bool use_hp(int T, int B, int I, int H, int D) {
   if (getenv("RNNT_GEMM_NO_HP")) return false;
   const long M = (long)T * B, N4 = (long)D * 4 * H;
+  // gemm_hp.hip addresses an operand's planes with 32-bit buffer offsets: a shape with a plane of 4 GB or more (e.g. bi-H = 1024,
+  // B = 64, T = 2048) stays on gemm.hip.  The bound is evaluated with the widest input a layer of this stack can see (I or D*H),
+  // so the sizing query (rnnt_hip_lstm_workspace_bytes) and every layer's launch take the same decision.
+  const long Iw = I > D * H ? I : (long)D * H;
+  const size_t lim = (size_t)1 << 32;
+  if (hp_plane_bytes(M, Iw) >= lim || hp_plane_bytes(Iw, M) >= lim || hp_plane_bytes(M, N4) >= lim || hp_plane_bytes(N4, M) >= lim ||
+      hp_plane_bytes(H, M) >= lim)
+    return false;
   return M >= 1024 && N4 >= 512 && H >= 128 && (getenv("RNNT_GEMM_FORCE_HP") || (M * N4 >= (1l << 22)));
 }
 
@@ -1577,7 +1585,7 @@ LstmWs carve_lstm(void* ws, int T, int B, int I, int H, int D, const Plan& pl) {
       if (h1 > sc) sc = h1;
       if (h2 > sc) sc = h2;
       const int64_t mn[3] = {N4 * I, (int64_t)4 * H * H, (int64_t)4 * H * H};   // the grouped launch keeps all slabs at once
-      const size_t h3 = hp_gemm_grouped_workspace_bytes(mn, 1 + D);
+      const size_t h3 = HPQ_HEADER_BYTES + hp_gemm_grouped_workspace_bytes(mn, 1 + D);   // queue counters in front of the slabs
       if (h3 > sc) sc = h3;
     }
     w.scratch_bytes = sc;
@@ -1933,8 +1941,10 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
       // the weight-gradient products of THIS layer may run beside the recurrence of the next one (same shape): that one sits on
       // XCDs 0 .. D*G-1 (launch_persistent2's stride-8 placement), the products keep to the others
       if (bd->beside_recurrence) {
+        // (only on a device that exposes all 8 XCDs — the 256-CU SPX mode the placement rule was measured on; a partitioned device
+        //  runs the products on every XCD it has, and gemm_hp.hip's check kernel raises the status word if a launch left units undone)
         const int used = recurrence_xcds(T, B, H, D, d->cell, cus);
-        if (used <= 4) xcd_skip = (1u << used) - 1u;
+        if (used <= 4 && cus == 256) xcd_skip = (1u << used) - 1u;
       }
     } else if (!do_recur) {
       // phase 2: nothing to launch here
@@ -2091,7 +2101,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
         return rc;
     }
     if (grouped) {
-      if ((rc = hp_gemm_grouped(pr, npr, xcd_skip, w.flags + 8, w.scratch, w.scratch_bytes, s))) return rc;
+      if ((rc = hp_gemm_grouped(pr, npr, xcd_skip, reinterpret_cast<unsigned*>(w.scratch), (char*)w.scratch + HPQ_HEADER_BYTES,
+                                w.scratch_bytes - HPQ_HEADER_BYTES, s, k.status)))
+        return rc;
       const long per = (long)4 * H * I;
       hipLaunchKernelGGL(unpermute_w_kernel, dim3((unsigned)ceil_div(per, 256), D), dim3(256), 0, s, w.wp, H, I, per, ngate,
                          bd->dw_ih[0], D > 1 ? bd->dw_ih[1] : bd->dw_ih[0], acc);

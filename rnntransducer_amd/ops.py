@@ -224,7 +224,10 @@ class LinearFn(torch.autograd.Function):
         # big products (the encoder's out_proj: 32000 x 512 x 1024 at config 2) take the half-pair f16 path of the LSTM layers'
         # products (include/rnnt_hip.h: same fp32-grade arithmetic, 440 instead of 140-150 TFLOP/s); its operand splits only pay
         # for themselves on deep, wide shapes
-        ctx.hp = M >= 1024 and N >= 256 and K >= 1024 and not os.environ.get("RNNT_GEMM_NO_HP")
+        # (an operand whose planes reach 4 GB is beyond gemm_hp.hip's 32-bit buffer offsets: such a product stays on gemm.hip)
+        hpb = _lib.lib().rnnt_hip_hp_bytes
+        ctx.hp = (M >= 1024 and N >= 256 and K >= 1024 and not os.environ.get("RNNT_GEMM_NO_HP")
+                  and max(hpb(M, K), hpb(K, M), hpb(M, N), hpb(N, M)) < (1 << 32))
         if ctx.hp:
             gemm_hp(hp_split(x.view(M, K)), hp_split(W0), out=y.view(M, N), bias=bias)
         else:
@@ -363,7 +366,10 @@ class LstmStackFn(torch.autograd.Function):
         params = weights
         weights = [_f32c(w, "lstm weight") for w in weights]
         dev = x.device
-        ws = lstm_workspace(T, B, max(I0, D * H), H, D, dev)
+        # one workspace for all layers: the larger of what the first (input width I0) and the inner layers (D*H) ask for
+        ws = lstm_workspace(T, B, I0, H, D, dev)
+        if num_layers > 1 and _lib.lib().rnnt_hip_lstm_workspace_bytes(T, B, D * H, H, D) > ws.numel():
+            ws = lstm_workspace(T, B, D * H, H, D, dev)
         saved = []
         cur = x
         for layer in range(num_layers):

@@ -16,6 +16,11 @@ OneCycleLR drives `lr` exactly as in the reference, `state_dict()` / `load_state
 fused HIP kernel over the flat buffers (`rnnt_hip_adamw_step_ex`), guarded on device by the persistent recurrences' sticky
 status word: if an LSTM kernel of this step gave up on an inter-workgroup wait, the update is skipped on device and the next
 `step()` raises RnntHipError — no host synchronisation on the way (one 4-byte asynchronous read-back per step).
+
+At world > 1 the status word is PART OF THE COLLECTIVE: the flat gradient buffer carries one extra slot behind the last
+parameter, every rank writes (its word != 0) there before the all-reduce, and after the SUM the slot holds the number of ranks
+whose recurrences gave up.  That slot — not the local word — is then the update kernel's guard and what `step()` reads back, so
+ALL ranks skip the update and ALL ranks raise at their next `step()`; no rank walks into the next all-reduce alone.
 """
 from typing import Iterable, List, Optional
 
@@ -38,8 +43,11 @@ class FlatParams:
         for n in self.sizes[:-1]:
             self.offsets.append(self.offsets[-1] + n)
         total = sum(self.sizes)
-        self.flat_param = torch.zeros(total, device=dev)
-        self.flat_grad = torch.zeros(total, device=dev)
+        self.n_param = total                       # elements the update kernel walks
+        # + 4 floats (one 16-byte granule) behind the last parameter; element `n_param` of flat_grad is the STATUS SLOT of the
+        # data-parallel exchange (see all_reduce_grads), the other three stay zero
+        self.flat_param = torch.zeros(total + 4, device=dev)
+        self.flat_grad = torch.zeros(total + 4, device=dev)
         self.direct_grads = bool(direct_grads)
         for p, off in zip(self.params, self.offsets):
             self.flat_param[off:off + p.numel()].copy_(p.data.reshape(-1))
@@ -80,12 +88,24 @@ class FlatParams:
             self.adopt()
         self.flat_grad.zero_()
 
-    def all_reduce_grads(self) -> float:
+    def status_slot(self) -> torch.Tensor:
+        """1-element view of flat_grad behind the last parameter: after `all_reduce_grads(status=...)` the number of ranks
+        whose status word was raised (0.0 = every rank's recurrences completed)."""
+        return self.flat_grad[self.n_param:self.n_param + 1]
+
+    def all_reduce_grads(self, status: Optional[torch.Tensor] = None) -> float:
         """DDP semantics (train.py:45): SUM over ranks in ONE collective over the flat buffer; returns the 1/world factor
-        that turns the sum into DDP's average (FlatAdamW folds it into the update kernel; `average_grads` applies it here)."""
+        that turns the sum into DDP's average (FlatAdamW folds it into the update kernel; `average_grads` applies it here).
+        `status`: this rank's device status word (any integer tensor, element 0 is read); (word != 0) rides in the buffer's
+        status slot, so that the SAME collective tells every rank whether any rank's gradients are invalid."""
         if self.world > 1:
             if not self.views_in_place():
                 self.adopt()
+            slot = self.status_slot()
+            if status is not None:
+                slot.copy_(status.reshape(-1)[:1].ne(0))   # on the gradients' stream, in front of the collective
+            else:
+                slot.zero_()
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
         return 1.0 / self.world
 
@@ -107,6 +127,7 @@ class FlatAdamW(torch.optim.AdamW):
         self.flat_v = torch.zeros_like(self.flat_param)
         self._steps = 0
         self._grad_scale = 1.0
+        self._reduced = False   # all_reduce_grads() ran since the last step(): the status slot of the collective is the guard
         self._point_state()
         self.world = self.flat.world
         self._status_host: Optional[torch.Tensor] = None   # pinned read-back slot of the device status word
@@ -145,8 +166,14 @@ class FlatAdamW(torch.optim.AdamW):
         self.flat.zero_grad()
 
     def all_reduce_grads(self) -> None:
-        """One RCCL all-reduce (SUM) over the flat gradient buffer; the 1/world of DDP's average rides in the next step()."""
-        self._grad_scale = self.flat.all_reduce_grads()
+        """One RCCL all-reduce (SUM) over the flat gradient buffer; the 1/world of DDP's average rides in the next step().
+        At world > 1 this rank's LSTM status word travels in the same collective (FlatParams.all_reduce_grads)."""
+        status = None
+        if self.world > 1 and self.flat_param.is_cuda:
+            from .ops import lstm_status_word
+            status = lstm_status_word(self.flat_param.device)
+        self._grad_scale = self.flat.all_reduce_grads(status)
+        self._reduced = self.world > 1
 
     def grad_bytes(self) -> int:
         return self.flat.grad_bytes()
@@ -157,12 +184,19 @@ class FlatAdamW(torch.optim.AdamW):
             return
         self._status_event.synchronize()  # recorded a whole step ago: already complete, costs nothing
         self._status_event = None
-        if int(self._status_host[0]) != 0:
+        if int(self._status_host[0]) != 0:   # uint32 view: a raised word, or the bits of a positive rank count
             from .ops import lstm_status_word
             lstm_status_word(self.flat_param.device).zero_()
-            raise _lib.RnntHipError("a persistent LSTM kernel of the previous step abandoned an inter-workgroup wait (4 s bound: "
+            # the device skipped that update: the host-side counters (bias correction of the NEXT update, state_dict's step) go
+            # back to the number of updates actually applied
+            self._steps -= 1
+            for p in self.flat.params:
+                self.state[p]["step"] -= 1
+            where = "of this rank or a peer (the word travels in the gradient all-reduce)" if self.world > 1 else "of the previous step"
+            raise _lib.RnntHipError(f"a persistent LSTM kernel {where} abandoned an inter-workgroup wait (4 s bound: "
                                     "its workgroups were not co-resident — is another kernel holding the CUs?).  That step's "
-                                    "gradients were invalid; its AdamW update was skipped on device, parameters are intact.")
+                                    "gradients were invalid; its AdamW update was skipped on device on every rank, parameters "
+                                    "are intact and the step counters were rewound.")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -182,14 +216,28 @@ class FlatAdamW(torch.optim.AdamW):
         g = self.param_groups[0]
         self._steps += 1
         b1, b2 = g["betas"]
-        status = lstm_status_word(self.flat_param.device)
+        # guard of the update kernel (*guard != 0 as uint32 -> skip): the local sticky word, or — after a data-parallel exchange —
+        # the collective's status slot (fp32 count of ranks with a raised word: 0.0 is all-zero bits, any count >= 1 is not), so
+        # that every rank takes the same decision
+        if self.world > 1 and not self._reduced:
+            # gradients were exchanged by someone else (DistributedDataParallel's reducer under a Lightning trainer): every rank is
+            # in step() now, so a 4-byte SUM of (word != 0) through the same slot keeps the ranks' decisions identical
+            slot = self.flat.status_slot()
+            slot.copy_(lstm_status_word(self.flat_param.device)[:1].ne(0))
+            dist.all_reduce(slot, op=dist.ReduceOp.SUM)
+            self._reduced = True
+        if self._reduced:
+            status = self.flat.status_slot().view(torch.int32)
+        else:
+            status = lstm_status_word(self.flat_param.device)[:1]
         _lib.check(_lib.lib().rnnt_hip_adamw_step_ex(_addr(self.flat_param), _addr(self.flat_grad), _addr(self.flat_m),
-                                                     _addr(self.flat_v), self.flat_param.numel(), float(g["lr"]), float(b1),
+                                                     _addr(self.flat_v), self.flat.n_param, float(g["lr"]), float(b1),
                                                      float(b2), float(g["eps"]), float(g["weight_decay"]), self._steps,
                                                      float(self._grad_scale), _addr(status), _stream()), "rnnt_hip_adamw_step_ex")
         self._grad_scale = 1.0
+        self._reduced = False
         if self._status_host is None:
-            self._status_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._status_host.copy_(status, non_blocking=True)
         self._status_event = torch.cuda.Event()
         self._status_event.record()

@@ -217,10 +217,15 @@ def test_raised_lstm_status_word_skips_the_update_and_raises_at_the_next_step():
         opt.step()                                          # update skipped on device; read-back enqueued
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
+        assert opt._steps == 2                              # the host counted the skipped update ...
         with pytest.raises(RnntHipError, match="abandoned an inter-workgroup wait"):
             opt.zero_grad()
             model.training_step(batch, 0)["loss"].backward()
             opt.step()
+        # ... and rewinds when the read-back shows the device skipped it: bias correction and state_dict's step count
+        # the updates actually applied
+        assert opt._steps == 1 and all(float(opt.state[p]["step"]) == 1.0 for p in opt.flat.params)
+        assert opt.state_dict()["state"][0]["step"] == 1.0
         assert int(word[0].item()) == 0                     # cleared by the raise: the caller may go on
         word[0] = 1
         with pytest.raises(RnntHipError):

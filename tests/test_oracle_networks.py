@@ -71,6 +71,29 @@ def test_joint_is_separable(golden_dir):
     np.testing.assert_allclose(A[:, :, None, :] + C[:, None, :, :] + bias, g["logits"], atol=1e-13)
 
 
+def test_per_utterance_lstm_equals_the_packed_one():
+    """oracle._per_utterance_lstm (used for the float64 checks at config 3 / 5 sizes, where autograd through a PackedSequence is
+    O(T^2) on the CPU) is the same function as the packed path the reference fixtures pin: outputs and every gradient to 1e-12,
+    ragged batch, 2 layers, both directions, LSTM and GRU."""
+    from oracle import rnnt_oracle as ro
+    for cell in (torch.nn.LSTM, torch.nn.GRU):
+        torch.manual_seed(3)
+        rnn = cell(6, 5, 2, batch_first=True, bidirectional=True).double()
+        x = torch.randn(4, 9, 6, dtype=torch.float64)
+        lens = [9, 4, 7, 1]
+        dy = torch.randn(4, 9, 10, dtype=torch.float64)
+        res = []
+        for fn in (ro._packed_lstm, ro._per_utterance_lstm):
+            rnn.zero_grad()
+            xr = x.clone().requires_grad_(True)
+            y = fn(rnn, xr, lens)
+            y.backward(dy)
+            res.append([y.detach(), xr.grad] + [p.grad.clone() for p in rnn.parameters()])
+        for a, b in zip(*res):
+            assert (a - b).abs().max().item() < 1e-12
+        assert torch.all(res[1][0][1, 4:] == 0) and torch.all(res[1][0][3, 1:] == 0)
+
+
 HIDDEN = {
     "h1_lstm_hidden": dict(embedding_size=10, pad_token_id=0, hidden_size=16, output_size=8, num_layers=2, rnn_type="lstm", dropout=0.0),
     "h2_gru_hidden": dict(embedding_size=12, pad_token_id=0, hidden_size=8, output_size=8, num_layers=1, rnn_type="gru", dropout=0.0),

@@ -7,7 +7,11 @@ as reported; both counters are in KB (1024 B).  Inputs are rocprofv3 `--output-f
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rnntransducer_amd.csrc.build import source_digest  # noqa: E402
 
 KINDS = (("gemm_hp_kernel", ("gemm_hp_kernel", "gemm_hp3_kernel")),
          ("gemm_bf16s_kernel", ("gemm_bf16s_kernel", "gemm_bf16s256_kernel")), ("gemm_f32_kernel", ("gemm_f32_kernel",)),
@@ -53,7 +57,7 @@ def main():
             detail[kind] = {"launches": launches, "read_bytes_per_launch": rd / launches, "write_bytes_per_launch": wr / launches}
     json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- {command}; FETCH_SIZE doubled per "
                          "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as reported; KB = 1024 B",
-               "from": out_path, "config": config, "hbm_bytes_per_launch": out, "detail": detail}, open(out_path, "w"), indent=1)
+               "from": out_path, "config": config, "csrc_sha16": source_digest(), "hbm_bytes_per_launch": out, "detail": detail}, open(out_path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
