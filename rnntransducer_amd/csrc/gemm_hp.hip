@@ -430,7 +430,14 @@ __global__ void __launch_bounds__(512, 1) gemm_hpq_kernel(const HpGemmQ q) {
     const int qi = (mine + hop) % nq;
     const int lo = (int)((long)total * qi / nq), hi = (int)((long)total * (qi + 1) / nq);
     while (true) {
-      if (threadIdx.x == 0) *next = lo + (int)atomicAdd(q.counter + qi, 1u);
+      if (threadIdx.x == 0) {
+        const int got = lo + (int)atomicAdd(q.counter + qi, 1u);
+        *next = got;
+        // units drawn (= units done once the kernel has ended), read by hpq_check_kernel behind this launch.  Counted HERE, inside the
+        // one divergent region of the loop: a second `if (threadIdx.x == 0)` region at the loop's end made hipcc 7.2 restructure the loop
+        // so that lanes != 0 re-entered the barriers without lane 0 ever refreshing *next (an endless loop on the same unit).
+        if (got < hi) atomicAdd(q.counter + 8, 1u);
+      }
       __syncthreads();
       const int u = __builtin_amdgcn_readfirstlane(*next);
       __syncthreads();
@@ -441,7 +448,6 @@ __global__ void __launch_bounds__(512, 1) gemm_hpq_kernel(const HpGemmQ q) {
       const int local = u - (pi ? q.unit_end[pi - 1] : 0);
       const int tn = local % p.tiles_n, z = (local / p.tiles_n) % p.splits, tm = local / (p.tiles_n * p.splits);
       hp_tile256(p, tn * p.tiles_m + tm, z, lds);
-      if (threadIdx.x == 0) atomicAdd(q.counter + 8, 1u);   // read by hpq_check_kernel behind this launch
     }
   }
 }

@@ -34,3 +34,20 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def usable_cores(cap: int = 16) -> int:
+    """CPUs this process may really use (affinity mask, clamped by a cgroup cpu.max quota): what the float64 oracles hand
+    torch.set_num_threads().  torch.get_num_threads() reports every logical CPU of the host (256 on the GPU box, whose cgroup
+    grants 16): more threads than cores made the config-3 / config-5 oracles 4-6x slower."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cap, n))

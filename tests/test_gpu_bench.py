@@ -29,9 +29,12 @@ def test_bench_emits_one_contract_line_with_roofline_and_cpu_baseline():
     assert j["loss_rel_delta"] < 1e-4          # north_star tolerance on the whole path (mel, label) -> loss
     assert "workload" in j["config"] and "model" not in j["config"]
     assert set(j["grad_max_abs_dev"]) == {"fc.weight", "encoder.rnn.weight_hh_l0", "decoder.embedding.weight"}
-    for v in j["grad_max_abs_dev"].values():   # vs the FLOAT64 oracle: the fixture tests' bound, or fp32's own distance
-        assert v["max_abs_dev"] <= max(2e-4 * max(v["ref_max_abs"], 1e-3), 1.5 * v["fp32_oracle_max_abs_dev"])
-    assert j["parity"]["ok"] is True
+    for v in j["grad_max_abs_dev"].values():   # vs the FLOAT64 oracle at the INITIAL weights: the fixture tests' bound, no widening
+        assert v["max_abs_dev"] <= 2e-4 * max(v["ref_max_abs"], 1e-3)
+    assert j["parity"]["ok"] is True and j["parity"]["all_rows_finite"] is True and "INITIAL weights" in j["parity"]["oracle"]
+    assert j["parity_after_training"]["informational"] is True      # reported next to the fp32 oracle's own distance, never a gate
+    assert "fp32_oracle_max_abs_dev" in j["parity_after_training"]["grad_max_abs_dev"]["fc.weight"]
+    assert j["rccl_ranks"] == 1
     assert j["cpu_baseline"]["cpu_model"] and j["cpu_baseline"]["host_logical_cpus"] >= 4
     assert "1 warm-up" in j["cpu_baseline"]["sample"] and "3 timed" in j["cpu_baseline"]["sample"]
     assert j["memory"]["peak_allocated_bytes"] > 0

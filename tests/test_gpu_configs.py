@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import usable_cores
 from oracle.rnnt_oracle import OracleJointNet, make_batch, rnnt_loss_c, training_loss
 
 pytestmark = pytest.mark.gpu
@@ -101,7 +102,7 @@ def _oracle_step(tn, pn, V, model, small, per_utterance, separable):
     from oracle import rnnt_oracle as ro
     oracle = OracleJointNet(dict(tn), dict(pn, pad_token_id=0), V).double()
     oracle.load_state_dict({k[len("jointnet."):]: v.double() for k, v in model.state_dict().items()})
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    torch.set_num_threads(usable_cores())
     ro.PER_UTTERANCE = per_utterance   # config 3 / 5 sizes: autograd through a PackedSequence is O(T^2) on the CPU (equality pinned
     try:                               # by tests/test_oracle_networks.py::test_per_utterance_lstm_equals_the_packed_one)
         ref = training_loss(oracle, (small[0].double(),) + small[1:], separable=separable)
@@ -240,7 +241,7 @@ def test_lstm_layer_at_the_timed_launch_geometry_vs_torch_float64(name, I, lens)
     lens = [lens[i] for i in perm]           # classes scattered over the rows, as a collate would hand them
     for b in range(B):
         x[b, lens[b]:] = 0
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    torch.set_num_threads(usable_cores())
     ref_out, ref_dx = _lstm_float64_by_length_class(ref, x, lens, dy)
     x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
     y = hip(x_tm, torch.tensor(lens, dtype=torch.int32, device="cuda"))
