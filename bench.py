@@ -144,7 +144,8 @@ def parity_vs_float64_oracle(model, opt, tn, pn, V, batch, nb, threads, with_fp3
     was_training = model.training
     model.eval()
     opt.zero_grad()
-    nll = model.jointnet.loss(batch[0], batch[2], batch[3], batch[5], batch[6], model.blank_token_id, reduction="none")
+    nll = model.jointnet.loss(batch[0], batch[2], batch[3], batch[5], batch[6], model.blank_token_id, reduction="none",
+                              audio_lengths=batch[1])   # with the host list, as training_step: ragged batches take the valid-frame plan
     hip_l = nll[:nb].mean()
     hip_l.backward()
     hip_loss = float(hip_l.detach())

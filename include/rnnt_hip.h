@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RNNT_HIP_ABI_VERSION 3
+#define RNNT_HIP_ABI_VERSION 4
 
 #define RNNT_OK 0
 #define RNNT_ERR_INVALID (-1)   /* bad argument (dims, alignment, null pointer)            */
@@ -203,6 +203,15 @@ typedef struct rnnt_lstm_desc {
   float x_abs_bound; /* optional (backward): > 0 = the caller guarantees |x| <= x_abs_bound everywhere (x is the dropped output of
                      * a bounded cell below: 1 / (1 - p)).  The half-pair planes of x^T then take this as their scale instead of
                      * a pass over x for its column maxima (absolute error of an element <= 2^-39 x_abs_bound either way).  0: measure. */
+  const int32_t* row_idx; /* optional, ragged batches (what pack_padded_sequence buys the reference, encoder.py:93-96,99-101, without a packed
+                     * copy): device table of the n_rows VALID time-major rows t*B + b (those with t < lens[b]), ascending.  The big products
+                     * (input projection, dX, dW_ih, dW_hh) then run over n_rows instead of T*B rows — operand tiles are gathered / results
+                     * scattered through this table — and every sync group of the recurrence runs max(lens of its rows) steps instead of T
+                     * (reverse direction: from that frame down).  Rows that are not listed are then NOT written in gates / cst / y_drop,
+                     * and y keeps what the caller put there: hand in y zero-filled (frames t >= lens[b] must read 0).  Results on valid
+                     * frames do not depend on it.  Honoured by the default kernels (v5 recurrences + half-pair products); other shapes
+                     * ignore it and compute all T*B rows.  NULL: all rows.  Same table for the forward and the backward call. */
+  int32_t n_rows;   /* entries of row_idx (= sum of lens); ignored when row_idx is NULL */
 } rnnt_lstm_desc;
 
 size_t rnnt_hip_lstm_workspace_bytes(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D);
@@ -211,6 +220,9 @@ int32_t rnnt_hip_lstm_max_batch(int32_t H, int32_t D, int32_t cell);
 /* XCDs (of 8) a recurrence of this shape leaves without a workgroup (0 when its groups fill the chip or are not placed per XCD):
  * what a caller looks at before it puts phase 2 of one layer beside phase 1 of the next (rnnt_lstm_bwd_desc.phase). */
 int32_t rnnt_hip_lstm_free_xcds(int32_t T, int32_t B, int32_t H, int32_t D, int32_t cell);
+/* 1 if a layer of this shape honours rnnt_lstm_desc.row_idx (v5 recurrences + half-pair products: every consumer of the stash gathers
+ * the valid rows), 0 if it ignores the table and computes all T*B rows. */
+int32_t rnnt_hip_lstm_takes_row_idx(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D, int32_t cell);
 int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream);
 
 typedef struct rnnt_lstm_bwd_desc {

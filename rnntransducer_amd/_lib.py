@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RNNT_HIP_LIB: another build of the same library (A/B variants made by `csrc/build.py --variant`); still no fallback of any kind
 LIB_PATH = os.environ.get("RNNT_HIP_LIB") or os.path.join(_HERE, "csrc", "librnnt_hip.so")
-ABI_VERSION = 3   # RNNT_HIP_ABI_VERSION of include/rnnt_hip.h
+ABI_VERSION = 4   # RNNT_HIP_ABI_VERSION of include/rnnt_hip.h
 
 GEMM_GELU_A, GEMM_GELU_B, GEMM_ACCUM, GEMM_MUL_DGELU, GEMM_EXACT_F32 = 1, 2, 4, 8, 16
 CELL_LSTM, CELL_GRU, CELL_RNN_TANH, CELL_RNN_RELU = 0, 1, 2, 3
@@ -35,7 +35,8 @@ class LstmDesc(C.Structure):
                 ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2), ("y", C.c_void_p),
                 ("y_drop", C.c_void_p), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
                 ("gates", C.c_void_p), ("cst", C.c_void_p), ("aux", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t), ("status", C.c_void_p), ("x_abs_bound", C.c_float)]
+                ("workspace_bytes", C.c_size_t), ("status", C.c_void_p), ("x_abs_bound", C.c_float), ("row_idx", C.c_void_p),
+                ("n_rows", c_i32)]
 
 
 class LstmBwdDesc(C.Structure):
@@ -88,6 +89,7 @@ SYMBOLS = {
     "rnnt_hip_lstm_workspace_bytes": (C.c_size_t, [c_i32] * 5),
     "rnnt_hip_lstm_max_batch": (c_i32, [c_i32, c_i32, c_i32]),
     "rnnt_hip_lstm_free_xcds": (c_i32, [c_i32] * 5),
+    "rnnt_hip_lstm_takes_row_idx": (c_i32, [c_i32] * 6),
     "rnnt_hip_lstm_fwd": (C.c_int, [C.POINTER(LstmDesc), C.c_void_p]),
     "rnnt_hip_lstm_bwd": (C.c_int, [C.POINTER(LstmBwdDesc), C.c_void_p]),
     "rnnt_hip_lstm_check": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -46,16 +46,22 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // half-pair (hp) operands and the f16-MFMA GEMM on them (gemm_hp.hip); used by lstm.hip for its big products
 size_t hp_plane_bytes(int64_t rows, int64_t K);
 int hp_colmax(const float* x, int64_t rows, int64_t C, int64_t ld, uint32_t* amax, hipStream_t s);   // amax[C] of the columns
-int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, void* planes, hipStream_t s);  // writes amax[rows]
+// Ragged batches: `rowidx` / `kidx` (device tables, or nullptr) list the VALID rows of a padded (T*B, .) tensor in time-major order.
+//   hp_split: only the `rows` listed rows are converted, in place (plane row and amax entry rowidx[i]);
+//   hp_split_t: contraction index k reads source row kidx[k] (+ shift), K = number of listed rows (planes packed along k);
+//   hp_split_both: M = number of listed rows; row-major half-lines in place, transposed planes packed along k;
+//   hp_gemm: row m of the product fetches plane row a_rowidx[m] of A (a_plane_rows = rows of those planes) and stores output row
+//            c_rowidx[m] — the fetch of an operand tile gathers, no packed copy of a row-major operand is ever made.
+int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, void* planes, hipStream_t s, const int* rowidx = nullptr);  // writes amax[rows]
 int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, int64_t shift, const uint32_t* amax, void* planes,
-               hipStream_t s);
+               hipStream_t s, const int* kidx = nullptr);
 // both orientations in one pass; rowmax[M] and colmax[C] given
 int hp_split_both(const float* x, int64_t M, int64_t C, int64_t ld, const uint32_t* rowmax, const uint32_t* colmax, void* planes_rm,
-                  void* planes_t, hipStream_t s);
+                  void* planes_t, hipStream_t s, const int* rowidx = nullptr);
 size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N, int64_t K, float* C,
             int64_t c_div, int64_t c_so, int64_t c_si, const float* bias, unsigned flags, void* workspace, size_t workspace_bytes,
-            hipStream_t s);
+            hipStream_t s, const int* a_rowidx = nullptr, int64_t a_plane_rows = 0, const int* c_rowidx = nullptr);
 // several NT products in ONE queue-driven launch (workgroups on the XCDs of `xcd_skip` leave at once): the weight-gradient
 // products that run beside the next layer's recurrence.  `counter`: 16 device words, zeroed here: [0..7] one queue per XCD, [8] units completed, [9] set to 1 by the check
 // kernel behind the launch when [8] != the number of units (a device that exposes fewer XCDs than `xcd_skip` assumes: every workgroup

@@ -79,12 +79,15 @@ __device__ __forceinline__ void hp_split8(const float (&x)[8], float scale, u32x
 
 // x (rows x K, row stride ld) -> planes[rows][Kp/32][hi 32 | lo 32] + amax[rows]; ONE WAVE per row: pass 1 row maximum
 // (wave reduce), pass 2 scale + split (the row is re-read from L1/L2)
+// rowidx (optional): only the `rows` listed rows are converted, each IN PLACE (source row rowidx[i] -> plane row rowidx[i], amax[rowidx[i]]):
+// the valid frames of a ragged batch; the GEMM then gathers exactly those plane rows (HpGemmK::a_rowidx).
 __global__ void __launch_bounds__(256) hp_split_kernel(const float* __restrict__ x, long rows, int K, long ld, unsigned* __restrict__ amax,
-                                                       char* __restrict__ out) {
+                                                       char* __restrict__ out, const int* __restrict__ rowidx) {
   const int Kp = (K + 31) & ~31, cpr = Kp >> 3;
   const int lane = threadIdx.x & 63;
   const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+  for (long ri = (long)blockIdx.x * 4 + (threadIdx.x >> 6); ri < rows; ri += (long)gridDim.x * 4) {
+    const long r = rowidx ? (long)rowidx[ri] : ri;
     const float* row = x + r * ld;
     unsigned m = 0;
     for (int c = lane; c < cpr; c += 64) {
@@ -125,8 +128,11 @@ __global__ void __launch_bounds__(256) hp_split_kernel(const float* __restrict__
 // transposed: x is (Ksrc rows x >= R cols, row stride ld); planes row r (= source column c0 + r), contraction index k in [0, K):
 // value x[k + shift][c0 + r] (0 when k + shift is outside [0, Ksrc)), scaled by amax[r] (the source column's maximum: hp_colmax).
 // Workgroup = 32 k x 256 source columns through LDS.
+// kidx (optional): contraction index k takes source row kidx[k] + shift instead of k + shift (the valid frames of a ragged batch,
+// packed along the contraction: K = their number).
 __global__ void __launch_bounds__(256) hp_split_t_kernel(const float* __restrict__ x, int R, int K, long ld, int Ksrc, int shift,
-                                                         const unsigned* __restrict__ amax, char* __restrict__ out) {
+                                                         const unsigned* __restrict__ amax, char* __restrict__ out,
+                                                         const int* __restrict__ kidx) {
   __shared__ float tile[32][257];
   const int kb = blockIdx.x, r0 = blockIdx.y * 256;
   const int tid = threadIdx.x;
@@ -135,10 +141,11 @@ __global__ void __launch_bounds__(256) hp_split_t_kernel(const float* __restrict
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int kk = 4 * q + (tid >> 6);
-    const int ksrc = kb * 32 + kk + shift;
+    const int kdst = kb * 32 + kk;
+    const int ksrc = (kidx ? (kdst < K ? kidx[kdst] : 0) : kdst) + shift;
     const int c = 4 * (tid & 63);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (kb * 32 + kk < K && ksrc >= 0 && ksrc < Ksrc) {
+    if (kdst < K && ksrc >= 0 && ksrc < Ksrc) {
       const float* src = x + (long)ksrc * ld + r0 + c;
       if (vec && r0 + c + 3 < R) {
         v = *reinterpret_cast<const f32x4*>(src);
@@ -174,8 +181,11 @@ __global__ void __launch_bounds__(256) hp_split_t_kernel(const float* __restrict
 // dW = dG^T . X): x (M x C, row stride ld) -> out_rm[M][Cp/32] lines scaled by rowmax[r]  and  out_t[C][Mp/32] lines scaled by
 // colmax[c]; both tables are GIVEN (the backward recurrence leaves them).  Workgroup = 32 rows x 256 columns: every thread loads 8
 // consecutive values of a row, emits their row-major half-line from registers and parks them in LDS for the transposed store.
+// rowidx (optional, M = its length): source row i of the walk is rowidx[i]; its row-major half-lines go to plane row rowidx[i] (in place,
+// scaled by rowmax[rowidx[i]]), the transposed planes are packed along the contraction (index i, M of them).
 __global__ void __launch_bounds__(256) hp_split_both_kernel(const float* __restrict__ x, int M, int C, long ld, const unsigned* __restrict__ rowmax,
-                                                            const unsigned* __restrict__ colmax, char* __restrict__ out_rm, char* __restrict__ out_t) {
+                                                            const unsigned* __restrict__ colmax, char* __restrict__ out_rm, char* __restrict__ out_t,
+                                                            const int* __restrict__ rowidx) {
   __shared__ float tile[32][257];
   const int kb = blockIdx.x, c0 = blockIdx.y * 256;
   const int tid = threadIdx.x;
@@ -184,9 +194,10 @@ __global__ void __launch_bounds__(256) hp_split_both_kernel(const float* __restr
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = 8 * q + (tid >> 5), col = 8 * (tid & 31);
-    const int r = kb * 32 + row, c = c0 + col;
+    const int ri = kb * 32 + row, c = c0 + col;
+    const int r = (rowidx && ri < M) ? rowidx[ri] : ri;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (r < M && c < C) {
+    if (ri < M && c < C) {
       const float* src = x + (long)r * ld + c;
       if (vec && c + 7 < C) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
@@ -197,7 +208,7 @@ __global__ void __launch_bounds__(256) hp_split_both_kernel(const float* __restr
           if (c + e < C) v[e] = src[e];
       }
     }
-    if (r < M && c < Cp) {
+    if (ri < M && c < Cp) {
       u32x4 hi, lo;
       hp_split8(v, hp_scale_from_amax(rowmax[r]), hi, lo);
       char* dst = out_rm + ((long)r * (Cp >> 5) + (c >> 5)) * 128 + 16 * ((c >> 3) & 3);
@@ -238,6 +249,8 @@ struct HpGemmK {
   float* slab;               // splits > 1: slab[z][M][N]
   int tiles_m, tiles_n;
   int group_m;               // > 0: tiles walked in bands of group_m tile rows (see hp_grouped_tile); 0: plain column-major order
+  const int* a_rowidx;       // optional: row m of the product reads plane row (and amax entry) a_rowidx[m] of A — the valid frames of a
+  const int* c_rowidx;       // ragged batch gathered by the operand fetch; and writes output row c_rowidx[m] (scatter).  nullptr: m
 };
 
 // same bijective XCD remap idea as gemm.hip: consecutive tiles of one XCD share operand panels through its L2
@@ -264,7 +277,9 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = (8 * j + wave) * 8 + (lane >> 3);
-      const int ma = min(m0 + row, p.M - 1), nb = min(n0 + row, p.N - 1);  // rows past the edge re-read the last row (never stored)
+      int ma = min(m0 + row, p.M - 1);
+      const int nb = min(n0 + row, p.N - 1);  // rows past the edge re-read the last row (never stored)
+      if (p.a_rowidx) ma = p.a_rowidx[ma];
       va[j] = (unsigned)ma * p.a_pitch + 16u * src_slot;
       vb[j] = (unsigned)nb * p.b_pitch + 16u * src_slot;
     }
@@ -354,8 +369,9 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
       const int m = m0 + wr * 128 + i * 16 + 4 * (lane >> 4) + reg;
       const bool mok = m < p.M;
       const int mc = mok ? m : 0;
-      const float sa = hp_inv_scale_from_amax(p.a_amax[mc]);
-      float* crow = mode == 0 ? slab + (long)mc * p.N : p.C + (long)(mc / p.c_div) * p.c_so + (long)(mc % p.c_div) * p.c_si;
+      const float sa = hp_inv_scale_from_amax(p.a_amax[p.a_rowidx ? p.a_rowidx[mc] : mc]);
+      const int mo = p.c_rowidx ? p.c_rowidx[mc] : mc;
+      float* crow = mode == 0 ? slab + (long)mc * p.N : p.C + (long)(mo / p.c_div) * p.c_so + (long)(mo % p.c_div) * p.c_si;
       float old[4] = {0.f, 0.f, 0.f, 0.f};
       if (mode == 2) {
 #pragma unroll
@@ -593,7 +609,8 @@ __global__ void __launch_bounds__(256) hp_splitk_reduce_kernel(const HpGemmK p) 
     float s = 0.f;
     for (int z = 0; z < p.splits; ++z) s += p.slab[(long)z * total + i];
     if (p.bias) s += p.bias[n];
-    const long off = (long)(m / p.c_div) * p.c_so + (long)(m % p.c_div) * p.c_si + n;
+    const int mo = p.c_rowidx ? p.c_rowidx[m] : m;
+    const long off = (long)(mo / p.c_div) * p.c_so + (long)(mo % p.c_div) * p.c_si + n;
     if (p.flags & RNNT_GEMM_ACCUM) s += p.C[off];
     p.C[off] = s;
   }
@@ -618,32 +635,32 @@ int hp_colmax(const float* x, int64_t rows, int64_t C, int64_t ld, uint32_t* ama
   return RNNT_OK;
 }
 
-int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, void* planes, hipStream_t s) {
+int hp_split(const float* x, int64_t rows, int64_t K, int64_t ld, uint32_t* amax, void* planes, hipStream_t s, const int* rowidx) {
   if (rows == 0) return RNNT_OK;
   const long blocks = ceil_div(rows, 4);
   ProfScope prof(RNNT_K_HP_SPLIT, 8.0 * (double)rows * (double)K, s);
   hipLaunchKernelGGL(hp_split_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, x, (long)rows, (int)K, (long)ld, amax,
-                     (char*)planes);
+                     (char*)planes, rowidx);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }
 
 int hp_split_t(const float* x, int64_t R, int64_t K, int64_t ld, int64_t Ksrc, int64_t shift, const uint32_t* amax, void* planes,
-               hipStream_t s) {
+               hipStream_t s, const int* kidx) {
   if (R == 0 || K == 0) return RNNT_OK;
   ProfScope prof(RNNT_K_HP_SPLIT, 8.0 * (double)R * (double)K, s);
   hipLaunchKernelGGL(hp_split_t_kernel, dim3((unsigned)ceil_div(K, 32), (unsigned)ceil_div(R, 256)), dim3(256), 0, s, x, (int)R, (int)K, (long)ld,
-                     (int)Ksrc, (int)shift, amax, (char*)planes);
+                     (int)Ksrc, (int)shift, amax, (char*)planes, kidx);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }
 
 int hp_split_both(const float* x, int64_t M, int64_t C, int64_t ld, const uint32_t* rowmax, const uint32_t* colmax, void* planes_rm,
-                  void* planes_t, hipStream_t s) {
+                  void* planes_t, hipStream_t s, const int* rowidx) {
   if (M == 0 || C == 0) return RNNT_OK;
   ProfScope prof(RNNT_K_HP_SPLIT, 12.0 * (double)M * (double)C, s);
   hipLaunchKernelGGL(hp_split_both_kernel, dim3((unsigned)ceil_div(M, 32), (unsigned)ceil_div(C, 256)), dim3(256), 0, s, x, (int)M, (int)C, (long)ld,
-                     rowmax, colmax, (char*)planes_rm, (char*)planes_t);
+                     rowmax, colmax, (char*)planes_rm, (char*)planes_t, rowidx);
   RNNT_CHECK_LAUNCH();
   return RNNT_OK;
 }
@@ -660,21 +677,23 @@ size_t hp_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 int hp_gemm(const void* A, const uint32_t* a_amax, const void* B, const uint32_t* b_amax, int64_t M, int64_t N, int64_t K, float* C,
             int64_t c_div, int64_t c_so, int64_t c_si, const float* bias, unsigned flags, void* workspace, size_t workspace_bytes,
-            hipStream_t s) {
+            hipStream_t s, const int* a_rowidx, int64_t a_plane_rows, const int* c_rowidx) {
   RNNT_CHECK_ARG(A && B && C && a_amax && b_amax, "gemm_hp: null operand");
+  RNNT_CHECK_ARG(!a_rowidx || a_plane_rows >= M, "gemm_hp: a gathered A operand needs the row count of its planes");
   RNNT_CHECK_ARG(M >= 1 && N >= 1 && K >= 1 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm_hp: bad dims");
   RNNT_CHECK_ARG(c_div >= 1, "gemm_hp: c_div must be >= 1");
   RNNT_CHECK_ARG(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 127) == 0, "gemm_hp: planes must be 128-byte aligned");
   HpGemmK k;
   k.M = (int)M; k.N = (int)N; k.nkt = (int)ceil_div(K, HP_BK);
-  const size_t ab = hp_plane_bytes(M, K), bb = hp_plane_bytes(N, K);
+  const size_t ab = hp_plane_bytes(a_rowidx ? a_plane_rows : M, K), bb = hp_plane_bytes(N, K);
   RNNT_CHECK_ARG(ab < (1ull << 32) && bb < (1ull << 32), "gemm_hp: an operand exceeds the 4 GB a buffer resource addresses");
   k.A = (const char*)A; k.a_pitch = (unsigned)k.nkt * 128u; k.a_bytes = (unsigned)ab;
   k.B = (const char*)B; k.b_pitch = (unsigned)k.nkt * 128u; k.b_bytes = (unsigned)bb;
   k.a_amax = a_amax; k.b_amax = b_amax;
   k.C = C; k.c_div = (int)(c_div > 0x7fffffff ? 0x7fffffff : c_div); k.c_so = c_so; k.c_si = c_si;
   k.bias = bias; k.flags = flags;
-  const bool k3 = getenv("RNNT_GEMM_HP_3STAGE") != nullptr;   // opt-in: 256x128 tiles / 3-stage LDS ring (measured 10-14 % slower than 256x256 / 2 stages)
+  k.a_rowidx = a_rowidx; k.c_rowidx = c_rowidx;
+  const bool k3 = getenv("RNNT_GEMM_HP_3STAGE") != nullptr && !a_rowidx && !c_rowidx;   // opt-in: 256x128 tiles / 3-stage LDS ring (measured 10-14 % slower than 256x256 / 2 stages)
   k.tiles_m = (int)ceil_div(M, HP_BM); k.tiles_n = (int)ceil_div(N, k3 ? HP3_BN : HP_BN);
   const int tiles = k.tiles_m * k.tiles_n;
   {  // band height of the tile walk: 8 x 4 tiles in flight per XCD when an XCD's share is >= 32 tiles, 4 x 2 for the small outputs
@@ -744,6 +763,7 @@ int hp_gemm_grouped(const HpProblem* pr, int n, unsigned xcd_skip, unsigned* cou
     k.a_amax = a.a_amax; k.b_amax = a.b_amax;
     k.C = a.C; k.c_div = 1; k.c_so = a.ldc; k.c_si = 0;
     k.bias = nullptr; k.flags = a.flags;
+    k.a_rowidx = k.c_rowidx = nullptr;
     k.tiles_m = (int)ceil_div(a.M, HP_BM); k.tiles_n = (int)ceil_div(a.N, HP_BN);
     total_kt += (long)k.tiles_m * k.tiles_n * k.nkt;
     flops += 2.0 * (double)a.M * (double)a.N * (double)a.K;

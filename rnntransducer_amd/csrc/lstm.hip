@@ -1667,6 +1667,7 @@ int check_desc(const rnnt_lstm_desc* d, Plan* pl, LstmWs* w) {
   RNNT_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "lstm: dropout_p must be in [0,1)");
   RNNT_CHECK_ARG(d->dropout_p == 0.f || d->y_drop, "lstm: dropout_p > 0 needs y_drop");
   RNNT_CHECK_ARG(d->x_abs_bound >= 0.f && d->x_abs_bound < 1e30f, "lstm: x_abs_bound must be 0 (measure) or a finite positive bound");
+  RNNT_CHECK_ARG(!d->row_idx || (d->n_rows >= 1 && d->n_rows <= (int64_t)d->T * d->B), "lstm: row_idx needs 1 <= n_rows <= T*B (got %d)", d->n_rows);
   *w = carve_lstm(d->workspace, d->T, d->B, d->I, d->H, d->D, *pl);
   RNNT_CHECK_ARG(d->workspace && d->workspace_bytes >= w->total, "lstm: workspace too small (%zu < %zu)",
                  d->workspace_bytes, w->total);
@@ -1700,8 +1701,21 @@ void fill_kernel_args(const rnnt_lstm_desc* d, const Plan& pl, const LstmWs& w, 
   k->allow_local = getenv("RNNT_LSTM_NO_XCD_LOCAL") ? 0 : 1;
   k->hw_math = getenv("RNNT_LSTM_EXACT_MATH") ? 0 : 1;
   k->pause = 0;
+  k->gbound = 0;
   k->colmax = k->colmax_h = nullptr;
   k->rowmax = nullptr;
+}
+
+// rnnt_lstm_desc.row_idx is honoured where EVERY consumer of the stash gathers the valid rows: v5 recurrences (group step bounds) with
+// the half-pair products (row gather in the operand fetch / k-gather in the transposed splits).  Same answer in the forward and the
+// backward call of a layer (it depends on the shape only).
+bool shape_takes_row_idx(int T, int B, int I, int H, int D, int cell, int cus) {
+  Plan2 p2;
+  return use_hp(T, B, I, H, D) && I >= 32 && T > 1 && make_plan3(B, H, D, cus, true, &p2) && lstm5_supported(T, B, H, D, cell);
+}
+bool ragged_plan(const rnnt_lstm_desc* d, const LstmWs& w, int cus) {
+  return d->row_idx && d->n_rows > 0 && d->n_rows < (int64_t)d->T * d->B && w.hp && d->x_sb == d->I && d->x_st == (int64_t)d->B * d->I &&
+         shape_takes_row_idx(d->T, d->B, d->I, d->H, d->D, d->cell, cus);
 }
 
 }  // namespace
@@ -1730,6 +1744,13 @@ static int recurrence_xcds(int T, int B, int H, int D, int cell, int cus) {
   if (!make_plan3(B, H, D, cus, true, &p2) || !lstm5_supported(T, B, H, D, cell)) return 8;
   const int NG = D * p2.G;
   return (NG <= 4 && p2.NC <= 32 && !getenv("RNNT_LSTM_NO_XCD_STRIDE")) ? NG : 8;   // launch_persistent2: stride 8, group g on XCD g
+}
+
+extern "C" int32_t rnnt_hip_lstm_takes_row_idx(int32_t T, int32_t B, int32_t I, int32_t H, int32_t D, int32_t cell) {
+  int cus = device_cus();
+  if (cus <= 0) cus = 256;
+  if (T < 1 || B < 1 || I < 1 || H < 4 || D < 1 || D > 2) return 0;
+  return shape_takes_row_idx(T, B, I, H, D, cell, cus) ? 1 : 0;
 }
 
 extern "C" int32_t rnnt_hip_lstm_free_xcds(int32_t T, int32_t B, int32_t H, int32_t D, int32_t cell) {
@@ -1784,12 +1805,15 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   }
   // 2. hoisted input projection for all timesteps: gates[(t,b)][d*4H + 4j+g] = x(t,b,:) . W_ih'[.] + bias'
   const bool x_plain = d->x_sb == I && d->x_st == (int64_t)d->B * I;
+  const bool ragged = ragged_plan(d, w, device_cus());   // valid frames only (rnnt_lstm_desc.row_idx)
   if (w.hp && x_plain && I >= 32) {  // f16 matrix cores on half-pair operands (gemm_hp.hip)
     const int64_t M = (int64_t)d->T * d->B, N4 = (int64_t)D * 4 * H;
+    const int64_t Mv = ragged ? d->n_rows : M;             // rows the product runs over
+    const int* ridx = ragged ? d->row_idx : nullptr;
     uint32_t* ax = w.hp_amax, *aw = w.hp_amax + M;
-    if (int rc = hp_split(d->x, M, I, I, ax, w.hp_x, s)) return rc;
+    if (int rc = hp_split(d->x, Mv, I, I, ax, w.hp_x, s, ridx)) return rc;   // planes / maxima of the valid rows, in place
     if (int rc = hp_split(w.wp, N4, I, I, aw, w.hp_w, s)) return rc;
-    if (int rc = hp_gemm(w.hp_x, ax, w.hp_w, aw, M, N4, I, d->gates, 1, N4, 0, w.bp, 0, nullptr, 0, s)) return rc;
+    if (int rc = hp_gemm(w.hp_x, ax, w.hp_w, aw, Mv, N4, I, d->gates, 1, N4, 0, w.bp, 0, nullptr, 0, s, ridx, M, ridx)) return rc;
   } else {
     rnnt_gemm_desc g = {};
     g.M = (int64_t)d->T * d->B; g.N = (int64_t)D * 4 * H; g.K = I;
@@ -1804,6 +1828,7 @@ extern "C" int rnnt_hip_lstm_fwd(const rnnt_lstm_desc* d, void* stream) {
   RNNT_CHECK_HIP(hipMemsetAsync(w.flags, 0, (size_t)(reinterpret_cast<char*>(w.hx) - reinterpret_cast<char*>(w.flags)) + w.hx_bytes, s));
   LstmK k;
   fill_kernel_args(d, pl, w, &k);
+  k.gbound = ragged ? 1 : 0;
   int rc = RNNT_OK;
   Plan2 p2;
   const int cus = device_cus();
@@ -1896,6 +1921,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   int rc = RNNT_OK;
   Plan2 p2;
   const int cus = device_cus();
+  const bool ragged = ragged_plan(d, w, cus);            // valid frames only (rnnt_lstm_desc.row_idx): as in the forward call
+  const int* ridx = ragged ? d->row_idx : nullptr;
+  k.gbound = ragged ? 1 : 0;
   auto adopt = [&](const Plan2& q) {
     k.NC = q.NC; k.Hs = q.HS; k.G = q.G; k.Bg = q.Bg; k.Kp = q.Kp;
   };
@@ -2001,6 +2029,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   if (rc) return rc;
 
   const int64_t M = (int64_t)T * B, N4 = (int64_t)D * 4 * H;
+  const int64_t Mv = ragged ? d->n_rows : M;   // rows (row-major operands: gathered by the GEMM) / contraction length (transposed planes: packed)
   const bool hp_in = w.hp && I >= 128;   // products with I as an output / contraction width on the f16 matrix cores
   // per-row maxima: dG rows | dG columns | W_ih'^T rows | X^T rows | h^T rows
   uint32_t* a_dgr = w.hp ? w.hp_amax + M + N4 : nullptr;
@@ -2011,14 +2040,14 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
   if (w.hp) {  // half-pair planes of dG in both orientations (gemm_hp.hip is NT-only: transposed operands are materialised)
     const bool both = rowmax_done && colmax_done && hp_in && bd->dx;   // (same in both phases of a two-phase backward)
     if (do_recur && hp_in && bd->dx) {
-      if (both) rc = hp_split_both(d->gates, M, N4, N4, a_dgr, a_dgc, w.hp_dg, w.hp_dgt, s);
-      else rc = hp_split(d->gates, M, N4, N4, a_dgr, w.hp_dg, s);
+      if (both) rc = hp_split_both(d->gates, Mv, N4, N4, a_dgr, a_dgc, w.hp_dg, w.hp_dgt, s, ridx);
+      else rc = hp_split(d->gates, Mv, N4, N4, a_dgr, w.hp_dg, s, ridx);
       if (rc) return rc;
     }
     if (do_weights && !colmax_done)
       if ((rc = hp_colmax(d->gates, M, N4, N4, a_dgc, s))) return rc;
     if (do_weights && !both)
-      if ((rc = hp_split_t(d->gates, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
+      if ((rc = hp_split_t(d->gates, N4, Mv, N4, M, 0, a_dgc, w.hp_dgt, s, ridx))) return rc;
   }
   // 2. dX = dG . W_ih'   (needs the permuted weights: rebuild them, the forward copy may have been overwritten)
   if (do_recur && bd->dx) {
@@ -2029,7 +2058,7 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     if (hp_in) {
       if ((rc = hp_colmax(w.wp, N4, I, I, a_w, s))) return rc;
       if ((rc = hp_split_t(w.wp, I, N4, I, N4, 0, a_w, w.hp_w, s))) return rc;   // W_ih'^T: (I, contraction N4)
-      if ((rc = hp_gemm(w.hp_dg, a_dgr, w.hp_w, a_w, M, I, N4, bd->dx, 1, I, 0, nullptr, 0, nullptr, 0, s))) return rc;
+      if ((rc = hp_gemm(w.hp_dg, a_dgr, w.hp_w, a_w, Mv, I, N4, bd->dx, 1, I, 0, nullptr, 0, nullptr, 0, s, ridx, M, ridx))) return rc;
     } else {
       rnnt_gemm_desc g = {};
       g.M = M; g.N = I; g.K = N4;
@@ -2055,9 +2084,9 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
         memcpy(&bits, &d->x_abs_bound, 4);
         RNNT_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)a_x, (int)bits, (size_t)I, s));
       } else if ((rc = hp_colmax(d->x, M, I, I, a_x, s))) return rc;
-      if ((rc = hp_split_t(d->x, I, M, I, M, 0, a_x, w.hp_x, s))) return rc;     // X^T: (I, contraction T*B)
+      if ((rc = hp_split_t(d->x, I, Mv, I, M, 0, a_x, w.hp_x, s, ridx))) return rc;     // X^T: (I, contraction over the (valid) frames)
       if (!grouped)
-        if ((rc = hp_gemm(w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, M, w.wp, 1, I, 0, nullptr, 0, w.scratch, w.scratch_bytes, s))) return rc;
+        if ((rc = hp_gemm(w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, Mv, w.wp, 1, I, 0, nullptr, 0, w.scratch, w.scratch_bytes, s))) return rc;
     } else {
       rnnt_gemm_desc g = {};
       g.M = N4; g.N = I; g.K = M;
@@ -2082,21 +2111,22 @@ extern "C" int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* bd, void* stream) {
     if (gru) {  // hidden-side gate gradients differ from the input-side ones in the n gate: their own transposed planes
       if (colmax_done) a_dgc = a_y + (int64_t)D * H;   // left there by the v5 recurrence
       else if ((rc = hp_colmax(ghid, M, N4, N4, a_dgc, s))) return rc;
-      if ((rc = hp_split_t(ghid, N4, M, N4, M, 0, a_dgc, w.hp_dgt, s))) return rc;
+      if ((rc = hp_split_t(ghid, N4, Mv, N4, M, 0, a_dgc, w.hp_dgt, s, ridx))) return rc;
     }
     HpProblem pr[HP_GROUP_MAX];
     int npr = 0;
-    if (grouped) pr[npr++] = HpProblem{w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, M, w.wp, I, 0u};
+    if (grouped) pr[npr++] = HpProblem{w.hp_dgt, a_dgc, w.hp_x, a_x, N4, I, Mv, w.wp, I, 0u};
     for (int dir = 0; dir < D; ++dir) {
       // h_prev of frame t is y[t-1] (forward direction) / y[t+1] (reverse): plane row j, index k = y[k -/+ B][dir*H + j], zero outside
       char* yt = w.hp_yt + (size_t)dir * hp_plane_bytes(H, M);
-      if ((rc = hp_split_t(d->y + (int64_t)dir * H, H, M, (int64_t)D * H, M, dir == 0 ? -B : B, a_y + (int64_t)dir * H, yt, s))) return rc;
-      const char* ag = w.hp_dgt + (size_t)dir * 4 * H * (size_t)ceil_div(M, 32) * 128;
+      // (ragged batches: frame (t, b) of the packed contraction takes y of padded row (t -/+ 1, b), which is a valid frame or holds 0)
+      if ((rc = hp_split_t(d->y + (int64_t)dir * H, H, Mv, (int64_t)D * H, M, dir == 0 ? -B : B, a_y + (int64_t)dir * H, yt, s, ridx))) return rc;
+      const char* ag = w.hp_dgt + (size_t)dir * 4 * H * (size_t)ceil_div(Mv, 32) * 128;
       if (grouped) {
-        pr[npr++] = HpProblem{ag, a_dgc + (int64_t)dir * 4 * H, yt, a_y + (int64_t)dir * H, 4 * H, H, M, w.dwhh + (int64_t)dir * 4 * H * H, H, 0u};
+        pr[npr++] = HpProblem{ag, a_dgc + (int64_t)dir * 4 * H, yt, a_y + (int64_t)dir * H, 4 * H, H, Mv, w.dwhh + (int64_t)dir * 4 * H * H, H, 0u};
         continue;
       }
-      if ((rc = hp_gemm(ag, a_dgc + (int64_t)dir * 4 * H, yt, a_y + (int64_t)dir * H, 4 * H, H, M, w.dwhh + (int64_t)dir * 4 * H * H, 1, H, 0,
+      if ((rc = hp_gemm(ag, a_dgc + (int64_t)dir * 4 * H, yt, a_y + (int64_t)dir * H, 4 * H, H, Mv, w.dwhh + (int64_t)dir * 4 * H * H, 1, H, 0,
                         nullptr, 0, w.scratch, w.scratch_bytes, s)))
         return rc;
     }

@@ -53,6 +53,16 @@ __device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, float sc
   }
 }
 
+// Steps a sync group runs: T, or — ragged batches, p.gbound — the longest of its rows (uniform over the group's workgroups: every
+// member reads the same <= 16 lengths).  Frames beyond it are never touched by the group: the host zero-fills y and gathers the valid
+// rows of everything else (rnnt_lstm_desc.row_idx).
+__device__ __forceinline__ int group_steps(const LstmK& p, int b0) {
+  if (!p.gbound) return p.T;
+  int m = 1;
+  for (int r = 0; r < p.Bg && b0 + r < p.B; ++r) m = max(m, min(p.lens[b0 + r], p.T));
+  return __builtin_amdgcn_readfirstlane(m);
+}
+
 // Waits until every lane's predicate holds (wave-level), re-running `load_and_check` (which (re)issues the lane's loads and returns
 // whether all its dwords carry the expected tag).  Bounded: gives up after SPIN_LIMIT_TICKS or when another workgroup raised the
 // status word, raising it itself.  Returns false on abort.
@@ -91,7 +101,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
   int* abort_lds = reinterpret_cast<int*>(wmax + 8);
   unsigned* pubs = reinterpret_cast<unsigned*>(abort_lds + 4);   // [16 rows][HS units] packed dwords (write-through path only)
 
-  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  const int H = p.H, B = p.B, D = p.D, Kp = p.Kp;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the per-wave role tests below become scalar branches
   const int NG = D * p.G;
@@ -100,6 +110,8 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
   const int d = gid / p.G, g = gid % p.G;
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
+  const int TT = p.T;                       // padded frames: strides of the stash
+  const int T = group_steps(p, b0);         // steps this sync group runs (ragged batches: the longest of its rows)
 
   // W_hh slice: lane -> gate column 16*mb + lrow (gate lrow&3 of unit 4*mb + (lrow>>2)), k = wave*Kw + 32*ks + 8*lq + e
   f16x8 whi[MB][NKS], wlo[MB][NKS];
@@ -170,12 +182,12 @@ __global__ void __launch_bounds__(64 * NWV) lstm_fwd5_kernel(const LstmK p) {
   constexpr int OOB = 0x7ffffff0;
   const int t_first = (d == 0) ? 0 : T - 1;
   const int tdir = (d == 0) ? 1 : -1;
-  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)T * B * D * 4 * H * 4), RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * T * B * H * 4) : 0, RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t yd_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ydrop, 0, p.ydrop ? (int)((long)T * B * D * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)TT * B * D * 4 * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * TT * B * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)TT * B * D * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t yd_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.ydrop, 0, p.ydrop ? (int)((long)TT * B * D * H * 4) : 0, RSRC_FLAGS);
   int g_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj) * 4) : OOB;
-  int c_off = valid ? (int)((((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
+  int c_off = valid ? (int)((((((long)d * TT + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
   int y_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * H + oj) * 4) : OOB;
   const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
   // exchange image laid out [k / 4][row][k % 4]: the 16-byte chunks of one k-quad of all rows are adjacent, so the lanes of one
@@ -394,7 +406,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   float* wmax = reinterpret_cast<float*>(rowexp + 32);
   int* abort_lds = reinterpret_cast<int*>(wmax + 8);
 
-  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  const int H = p.H, B = p.B, D = p.D, Kp = p.Kp;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NG = D * p.G;
@@ -403,6 +415,8 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   const int d = gid / p.G, g = gid % p.G;
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
+  const int TT = p.T;                       // padded frames: strides of the stash
+  const int T = group_steps(p, b0);         // steps this sync group runs (ragged batches: the longest of its rows)
 
   // W_hh slice as the A operand: lane -> output unit u = 16*(wave*NMB + mb) + lrow (a COLUMN of W_hh),
   // k = 32*ks + 8*lq + e = own gate column 4*unit + gate  ->  W_hh[gate*H + j0 + (k>>2)][u]
@@ -471,13 +485,13 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5_kernel(const LstmK p) {
   f32x4 cmx = {0.f, 0.f, 0.f, 0.f}, cmxh = {0.f, 0.f, 0.f, 0.f};   // running |dG| maxima of this cell's 4 gate columns
   const int t_first = (d == 0) ? T - 1 : 0;
   const int tdir = (d == 0) ? -1 : 1;
-  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)T * B * D * 4 * H * 4), RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, CELL == 1 ? (int)((long)T * B * D * 4 * H * 4) : 0, RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * T * B * H * 4) : 0, RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)TT * B * D * 4 * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, CELL == 1 ? (int)((long)TT * B * D * 4 * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * TT * B * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)TT * B * D * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)TT * B * D * H * 4), RSRC_FLAGS);
   int g_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj) * 4) : OOB;
-  int c_off = valid ? (int)((((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
+  int c_off = valid ? (int)((((((long)d * TT + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
   int y_off = valid ? (int)(((((long)t_first * B + ob) * D + d) * H + oj) * 4) : OOB;
   const int g_step = valid ? tdir * B * D * 4 * H * 4 : 0, c_step = valid ? tdir * H * B * 4 : 0, y_step = valid ? tdir * B * D * H * 4 : 0;
 
@@ -788,7 +802,7 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5f_kernel(const LstmK p) {
   float* wmax = reinterpret_cast<float*>(rowexp + 32);
   int* abort_lds = reinterpret_cast<int*>(wmax + 8);
 
-  const int H = p.H, B = p.B, D = p.D, T = p.T, Kp = p.Kp;
+  const int H = p.H, B = p.B, D = p.D, Kp = p.Kp;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NG = D * p.G;
@@ -797,6 +811,8 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5f_kernel(const LstmK p) {
   const int d = gid / p.G, g = gid % p.G;
   const int b0 = g * p.Bg, j0 = wg * HS;
   const int lrow = lane & 15, lq = lane >> 4;
+  const int TT = p.T;                       // padded frames: strides of the stash
+  const int T = group_steps(p, b0);         // steps this sync group runs (ragged batches: the longest of its rows)
 
   // W_hh slice as the A operand (as lstm_bwd5_kernel): lane -> output unit u = 16*(wave*NMB + mb) + lrow,
   // k = 32*ks + 8*lq + e = own gate column 4*unit + gate  ->  W_hh[gate*H + j0 + (k>>2)][u]
@@ -867,14 +883,14 @@ __global__ void __launch_bounds__(64 * NWV) lstm_bwd5f_kernel(const LstmK p) {
   f32x4 cmx = {0.f, 0.f, 0.f, 0.f}, cmxh = {0.f, 0.f, 0.f, 0.f};
   const int t_first = (d == 0) ? T - 1 : 0;
   const int tdir = (d == 0) ? -1 : 1;
-  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)T * B * D * 4 * H * 4), RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, CELL == 1 ? (int)((long)T * B * D * 4 * H * 4) : 0, RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * T * B * H * 4) : 0, RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)T * B * D * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, (int)((long)TT * B * D * 4 * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.aux, 0, CELL == 1 ? (int)((long)TT * B * D * 4 * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, CELL == 0 ? (int)((long)D * TT * B * H * 4) : 0, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)TT * B * D * H * 4), RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((long)TT * B * D * H * 4), RSRC_FLAGS);
   const bool addressed = valid;
   int g_off = addressed ? (int)(((((long)t_first * B + ob) * D + d) * 4 * H + 4 * oj) * 4) : OOB;
-  int c_off = addressed ? (int)((((((long)d * T + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
+  int c_off = addressed ? (int)((((((long)d * TT + t_first) * (H / 4) + (oj >> 2)) * B + ob) * 4 + (oj & 3)) * 4) : OOB;
   int y_off = addressed ? (int)(((((long)t_first * B + ob) * D + d) * H + oj) * 4) : OOB;
   const int g_step = addressed ? tdir * B * D * 4 * H * 4 : 0, c_step = addressed ? tdir * H * B * 4 : 0, y_step = addressed ? tdir * B * D * H * 4 : 0;
 

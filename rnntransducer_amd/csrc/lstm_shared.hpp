@@ -40,6 +40,7 @@ struct LstmK {
                        // directions (zeroed by the host) — the row scales of the half-pair dG planes
   int pause;       // v5: s_sleep units (64 cycles) between a step's publication and its first poll round: low byte forward / backward
                    // consumers of early blocks, second byte backward consumers of late blocks (RNNT_LSTM_FWD_PAUSE, RNNT_LSTM_BWD_PAUSE=e,l)
+  int gbound;      // v5: 1 = every sync group runs max(lens of its rows) steps instead of T (ragged batches, rnnt_lstm_desc.row_idx)
   int hw_math;     // v2: v_exp_f32 / v_rcp_f32 cell math (default; measured whole-model loss delta identical to the ocml expf +
                    // IEEE-division form, which RNNT_LSTM_EXACT_MATH=1 selects)
 };

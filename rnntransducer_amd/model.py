@@ -108,7 +108,8 @@ class RNNTransducer(_Base):
         assert not getattr(self.args, "move_metrics_to_cpu", False), "DDP only (model.py:53)"
         input_audios, audio_lengths, tensor_audio_lengths, input_texts, text_lengths, targets, target_lengths = batch
         loss = self.jointnet.loss(input_audios, tensor_audio_lengths, input_texts, targets, target_lengths,
-                                  self.blank_token_id, reduction="mean")  # reduction="mean" (model.py:39), inside the library
+                                  self.blank_token_id, reduction="mean",   # reduction="mean" (model.py:39), inside the library
+                                  audio_lengths=audio_lengths if isinstance(audio_lengths, (list, tuple)) else None)
         if pl is not None and getattr(self, "_trainer", None) is not None:
             self.log("train_loss", loss, sync_dist=True)
         return {"loss": loss}

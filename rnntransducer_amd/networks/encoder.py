@@ -43,8 +43,9 @@ class AudioTransNet(nn.Module):
                                                          bidirectional=bidirectional)
         self.out_proj = HipLinear(2 * hidden_size if bidirectional else hidden_size, output_size)
 
-    def forward_time_major(self, inputs: torch.Tensor, lens_dev: torch.Tensor) -> torch.Tensor:
-        """(B,T,F) mel + int32 device lengths -> (T,B,O) time-major (what the fused joint+loss consumes)."""
+    def forward_time_major(self, inputs: torch.Tensor, lens_dev) -> torch.Tensor:
+        """(B,T,F) mel + int32 device lengths (or an ops.RaggedPlan built from the host list of lengths) -> (T,B,O) time-major
+        (what the fused joint+loss consumes)."""
         x_tm = inputs.transpose(0, 1).contiguous()
         return self.out_proj(self.rnn(x_tm, lens_dev))
 

@@ -49,9 +49,11 @@ class HipLSTM(nn.Module):
                     out.append(getattr(self, f"{name}_l{layer}{suffix}"))
         return out
 
-    def forward(self, x_tm: torch.Tensor, lens: torch.Tensor, want_final: bool = False):
-        """x_tm (T,B,I) time-major fp32, lens (B) int32 on the same device -> (T,B,D*H), zeros for t >= lens[b].
+    def forward(self, x_tm: torch.Tensor, lens, want_final: bool = False):
+        """x_tm (T,B,I) time-major fp32, lens (B) int32 on the same device — or an ops.RaggedPlan (lengths + valid-frame table:
+        padded frames are then skipped by the big products and the recurrences) -> (T,B,D*H), zeros for t >= lens[b].
         want_final: -> (y, h_n, c_n) with the (L*D, B, H) states after each sequence's own last step (c_n empty unless LSTM)."""
+        from ..ops import RaggedPlan
         p = self.dropout if (self.training and self.num_layers > 1) else 0.0
         self._step += 1
         seed = (torch.initial_seed() * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFFFFFF
@@ -62,6 +64,8 @@ class HipLSTM(nn.Module):
         if B <= cap:
             return LstmStackFn.apply(x_tm, lens, self.hidden_size, self.num_layers, self.bidirectional, p, seed, self.CELL,
                                      want_final, *self.flat_weights())
+        if isinstance(lens, RaggedPlan):   # the table indexes the whole batch: slices of it run dense
+            lens = lens.lens
         # batch rows are independent: run slices of the batch back to back (autograd sums the weight gradients)
         outs = []
         for b0 in range(0, B, cap):

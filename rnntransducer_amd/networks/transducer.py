@@ -48,15 +48,36 @@ class JointNet(nn.Module):
         return JointLogitsFn.apply(enc, dec, self.fc.weight, self.fc.bias)
 
     def loss(self, input_audios, tensor_audio_lengths, input_texts, targets, target_lengths, blank: int,
-             reduction: str = "none") -> torch.Tensor:
+             reduction: str = "none", audio_lengths=None) -> torch.Tensor:
         """-log P(y|x) through the fused path (no (B,T,U+1,V) tensor): per utterance, shape (B,) (reduction "none"), or the 0-d
-        "mean" / "sum" over the batch (model.py:39 builds the reference's loss with reduction="mean")."""
+        "mean" / "sum" over the batch (model.py:39 builds the reference's loss with reduction="mean").
+        `audio_lengths`: the python list of frame counts the reference's collate hands over next to the tensor (dataloader.py:20,49).
+        With it a ragged batch is handled as the reference handles it (networks/encoder.py:93-96: sort by length, pack): rows are
+        sorted by descending length so that the recurrences' sync groups are length-homogeneous, and a valid-frame table lets the
+        big products and the recurrences skip the padding (ops.RaggedPlan) — all planned on the host, no device synchronisation.
+        Results do not depend on it."""
         dev = input_audios.device
         t_lens = lengths_to_device(tensor_audio_lengths, dev)
         u_lens = lengths_to_device(target_lengths, dev)
-        enc = self.encoder.forward_time_major(input_audios, t_lens)
+        enc_lens, inv = t_lens, None
+        T, B = input_audios.size(1), input_audios.size(0)
+        if audio_lengths is not None and len(audio_lengths) == B and B > 1 and min(audio_lengths) < T:
+            from ..ops import RaggedPlan
+            host = [int(n) for n in audio_lengths]
+            order = sorted(range(B), key=lambda b: (-host[b], b))
+            if order != list(range(B)):   # length-sorted rows (encoder.py:94-96); the small per-utterance tensors follow, nll is un-sorted below
+                perm = torch.tensor(order, dtype=torch.int64, device=dev)
+                input_audios, input_texts, targets = (x.index_select(0, perm) for x in (input_audios, input_texts, targets))
+                t_lens, u_lens = t_lens.index_select(0, perm), u_lens.index_select(0, perm)
+                host = [host[b] for b in order]
+                if reduction == "none":
+                    inv = torch.empty_like(perm)
+                    inv[perm] = torch.arange(B, dtype=torch.int64, device=dev)
+            enc_lens = RaggedPlan(host, T, dev)
+        enc = self.encoder.forward_time_major(input_audios, enc_lens)
         dec = self.decoder.forward_time_major(input_texts, u_lens + 1)  # text length = label length + 1 (dataloader.py:39-40)
-        return JointLossFn.apply(enc, dec, self.fc.weight, self.fc.bias, targets, t_lens, u_lens, blank, torch.is_grad_enabled(), reduction)
+        out = JointLossFn.apply(enc, dec, self.fc.weight, self.fc.bias, targets, t_lens, u_lens, blank, torch.is_grad_enabled(), reduction)
+        return out if inv is None else out.index_select(0, inv)
 
     @torch.no_grad()
     def recognize_greedy(self, inputs: torch.Tensor, inputs_lengths, blank_token_id: int, max_iters: int = 3,

@@ -304,6 +304,25 @@ class EmbeddingFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 # LSTM stack (replaces nn.LSTM over a PackedSequence: encoder.py:67-75,93-102; decoder.py:71-79,105-120)
 # --------------------------------------------------------------------------------------------------
+class RaggedPlan:
+    """Valid-frame table of a padded time-major batch (rnnt_lstm_desc.row_idx): what pack_padded_sequence buys the reference
+    (networks/encoder.py:93-96,99-101) without a packed copy.  Built on the HOST from the python list of lengths the reference's
+    collate hands over (dataloader.py:20) — no device synchronisation — and uploaded once per batch: `row_idx` lists the rows
+    t*B + b with t < lens[b] in ascending order, `n_rows` = sum(lens).  Pass it to HipLSTM / LstmStackFn in place of `lens`."""
+
+    def __init__(self, lens_host: Sequence[int], T: int, device):
+        import numpy as np
+        lens_np = np.asarray(list(lens_host), dtype=np.int64)
+        if lens_np.ndim != 1 or lens_np.size < 1 or lens_np.min() < 1 or lens_np.max() > T:
+            raise ValueError(f"lengths must lie in [1, {T}]")
+        self.T, self.B = int(T), int(lens_np.size)
+        idx = np.flatnonzero((np.arange(T, dtype=np.int64)[:, None] < lens_np[None, :]).reshape(-1)).astype(np.int32)
+        self.n_rows = int(idx.size)
+        self.dense = self.n_rows == self.T * self.B
+        self.lens = torch.from_numpy(lens_np.astype(np.int32)).to(device, non_blocking=True)
+        self.row_idx = None if self.dense else torch.from_numpy(idx).to(device, non_blocking=True)
+
+
 def lstm_workspace(T: int, B: int, I: int, H: int, D: int, device) -> torch.Tensor:
     n = _lib.lib().rnnt_hip_lstm_workspace_bytes(T, B, I, H, D)
     if n == 0:
@@ -312,8 +331,10 @@ def lstm_workspace(T: int, B: int, I: int, H: int, D: int, device) -> torch.Tens
     return torch.empty(n, device=device, dtype=torch.uint8)
 
 
-def _fill_lstm_desc(d: LstmDesc, T, B, I, H, D, lens, x, weights, y, y_drop, p, seed, gates, cst, ws, cell=0, aux=None) -> None:
+def _fill_lstm_desc(d: LstmDesc, T, B, I, H, D, lens, x, weights, y, y_drop, p, seed, gates, cst, ws, cell=0, aux=None, plan=None) -> None:
     d.T, d.B, d.I, d.H, d.D = T, B, I, H, D
+    if plan is not None and plan.row_idx is not None:
+        d.row_idx, d.n_rows = _addr(plan.row_idx), plan.n_rows
     d.cell = cell
     d.aux = _addr(aux)
     d.lens = _addr(lens)
@@ -341,6 +362,13 @@ class LstmStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lens, hidden, num_layers, bidirectional, dropout_p, seed, cell, want_final, *weights):
+        plan = None
+        if isinstance(lens, RaggedPlan):   # ragged batch with its valid-frame table: the big products and the recurrences skip padding
+            plan, lens = lens, lens.lens
+            if (plan.T, plan.B) != tuple(x.shape[:2]):
+                raise ValueError(f"RaggedPlan was built for (T,B) = ({plan.T},{plan.B}), x is {tuple(x.shape)}")
+            if plan.dense:
+                plan = None
         _need_gpu(x, lens, *weights)
         if lens.dtype != torch.int32:
             raise ValueError(f"lengths must be int32 (dataloader.py:23-24), got {lens.dtype}")
@@ -377,16 +405,18 @@ class LstmStackFn(torch.autograd.Function):
             wl = weights[4 * D * layer:4 * D * (layer + 1)]
             gates = torch.empty(T, B, D * 4 * H, device=dev, dtype=torch.float32)
             cst = torch.empty(D * T * B * H, device=dev, dtype=torch.float32) if cell == 0 else None
-            y = torch.empty(T, B, D * H, device=dev, dtype=torch.float32)
+            # (with a valid-frame table the recurrence leaves frames beyond a sync group's longest row untouched: they must read 0)
+            y = (torch.zeros if plan is not None else torch.empty)(T, B, D * H, device=dev, dtype=torch.float32)
             p = dropout_p if layer < num_layers - 1 else 0.0
             y_drop = torch.empty_like(y) if p > 0 else None
             d = LstmDesc()
-            _fill_lstm_desc(d, T, B, I, H, D, lens, cur, wl, y, y_drop, p, seed + layer, gates, cst, ws, cell)
+            _fill_lstm_desc(d, T, B, I, H, D, lens, cur, wl, y, y_drop, p, seed + layer, gates, cst, ws, cell, plan=plan)
             check(_lib.lib().rnnt_hip_lstm_fwd(C.byref(d), _stream()), "rnnt_hip_lstm_fwd")
             saved.append((cur, y, gates, cst, p))
             cur = y_drop if p > 0 else y
         ctx.meta = (T, B, H, D, num_layers, seed, cell)
         ctx.lens = lens
+        ctx.plan = plan
         ctx.ws = ws
         ctx.saved = saved
         ctx.weights = weights
@@ -440,7 +470,7 @@ class LstmStackFn(torch.autograd.Function):
             bd = LstmBwdDesc()
             aux = torch.empty_like(gates) if cell == 1 else None
             _fill_lstm_desc(bd.f, T, B, I, H, D, ctx.lens, x_l, wl, y_l, y_l if p > 0 else None, p, seed + layer, gates,
-                            cst, wss[layer % 2], cell, aux)
+                            cst, wss[layer % 2], cell, aux, plan=ctx.plan)
             if layer > 0 and cell != 3:   # x of this layer is the (dropped) output of a bounded cell: |x| <= 1 / (1 - p) of the layer below
                 bd.f.x_abs_bound = 1.0 / (1.0 - ctx.saved[layer - 1][4])
             bd.dy = _addr(dy)

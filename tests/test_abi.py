@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in rnnt_hip.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert _lib.lib().rnnt_hip_version() == 3
+    assert _lib.lib().rnnt_hip_version() == _lib.ABI_VERSION == 4
 
 
 def test_argument_validation_happens_before_any_device_work():
@@ -112,3 +112,21 @@ def test_reference_style_checkpoint_round_trip(tmp_path):
     assert set(blob2["state_dict"]) == set(sd) and all(torch.equal(blob2["state_dict"][k], sd[k]) for k in sd)
     d = RNNTransducer.from_reference_checkpoint(str(out))
     assert all(torch.equal(v, sd[k]) for k, v in d.state_dict().items())
+
+
+def test_ragged_plan_lists_the_valid_time_major_rows():
+    """ops.RaggedPlan (rnnt_lstm_desc.row_idx): rows t*B + b with t < lens[b], ascending — the frames pack_padded_sequence keeps
+    (networks/encoder.py:99), in the same time-major order, built on the host from the collate's python list."""
+    import torch
+    from torch.nn.utils.rnn import pack_padded_sequence
+    from rnntransducer_amd.ops import RaggedPlan
+    lens, T = [7, 3, 5, 7, 1], 7
+    plan = RaggedPlan(lens, T, "cpu")
+    assert plan.n_rows == sum(lens) and not plan.dense and plan.lens.dtype == torch.int32 and plan.row_idx.dtype == torch.int32
+    x = torch.arange(T * len(lens), dtype=torch.float32).reshape(T, len(lens), 1)   # value = its own time-major row index
+    packed = pack_padded_sequence(x, torch.tensor(lens), enforce_sorted=False)      # rows sorted by length inside every time slab
+    assert sorted(packed.data.reshape(-1).to(torch.int32).tolist()) == plan.row_idx.tolist()
+    assert plan.row_idx.tolist() == sorted(plan.row_idx.tolist())
+    assert RaggedPlan([4, 4], 4, "cpu").dense and RaggedPlan([4, 4], 4, "cpu").row_idx is None
+    with pytest.raises(ValueError):
+        RaggedPlan([5, 2], 4, "cpu")

@@ -82,6 +82,18 @@ def test_fused_joint_loss_at_baseline_lattice_shapes(cfg):
     assert td.grad[u_lens[1] + 1:, 1].abs().max().item() == 0.0
 
 
+def _two_utterances_equal_frames_ragged_labels(T, U, V, seed):
+    """Two utterances of T frames each, the second with 2U/3 labels.  Equal frame counts let the float64 oracle run its LSTMs as one
+    plain batch (its autograd costs ~60 us per timestep node: config 3 / 5 sizes with per-utterance calls took 2-3 minutes on the GPU
+    box); ragged FRAME counts at these sizes are covered by the LSTM-level tests and by config 2 above."""
+    a, a_list, a_len, texts, t_list, targets, u_len = make_batch(2, T, U, V, ragged=False, seed=seed)
+    u1 = (2 * U) // 3
+    targets[1, u1:] = 0
+    texts[1, u1 + 1:] = 0
+    u_len[1] = u1
+    return (a, a_list, a_len, texts, [U + 1, u1 + 1], targets, u_len)
+
+
 def _embed_rows(small, big):
     """The 7-tuple `big` with its first rows replaced by the rows of `small` (same T, U): the batch the HIP path runs while the
     float64 oracle runs `small` alone."""
@@ -118,7 +130,7 @@ def _hip_step_on_first_rows(model, batch, n):
     for p in model.parameters():
         p.grad = None
     dev = tuple(x.cuda() if isinstance(x, torch.Tensor) else x for x in batch)
-    nll = model.jointnet.loss(dev[0], dev[2], dev[3], dev[5], dev[6], model.blank_token_id, reduction="none")
+    nll = model.jointnet.loss(dev[0], dev[2], dev[3], dev[5], dev[6], model.blank_token_id, reduction="none", audio_lengths=dev[1])
     loss = nll[:n].mean()
     loss.backward()
     torch.cuda.synchronize()
@@ -169,14 +181,14 @@ def test_full_model_config2_dims_step_vs_float64_oracle():
 def test_full_model_config3_geometry_step_vs_float64_oracle():
     """BASELINE configs[2] geometry: B=8 (the recurrences' 4-row sync groups), T=2000, U=120, V=72, 4x512 bi-LSTM / 1x512, INITIAL
     weights, dropout off.  float64 oracle (separable joint: the concat is 7.9 GB per copy at this size) on utterances 0-1 (second one
-    ragged); the HIP path runs all 8 rows with upstream weight 0 on rows 2-7.  Loss 1e-5 relative, every gradient 2e-4 of its maximum."""
+    with 2U/3 labels); the HIP path runs all 8 rows with upstream weight 0 on rows 2-7.  Loss 1e-5 relative, every gradient 2e-4 of its maximum."""
     from rnntransducer_amd import RNNTransducer
     V = 72
     tn = dict(input_size=80, hidden_size=512, output_size=512, num_layers=4, rnn_type="lstm", dropout=0.0, bidirectional=True)
     pn = dict(embedding_size=V, hidden_size=512, output_size=512, num_layers=1, rnn_type="lstm", dropout=0.0)
     torch.manual_seed(1)
     model = RNNTransducer(dict(pn), dict(tn), dict(num_classes=V), ARGS)
-    small = make_batch(2, 2000, 120, V, ragged=True, seed=11)
+    small = _two_utterances_equal_frames_ragged_labels(2000, 120, V, seed=11)
     ref_loss, ref_grads = _oracle_step(tn, pn, V, model, small, per_utterance=True, separable=True)
     model = model.cuda().train()
     big = _embed_rows(small, make_batch(8, 2000, 120, V, ragged=False, seed=12))
@@ -187,7 +199,7 @@ def test_full_model_config3_geometry_step_vs_float64_oracle():
 
 def test_full_model_config5_dims_step_vs_float64_oracle():
     """BASELINE configs[4] layer sizes: 6x640 bi-LSTM encoder (20-unit workgroups, K padded to 768), 1x640 prediction net, O=640,
-    V=2048 (vocab-tiled lattice kernels), T=1500, U=80, two utterances (second one ragged), INITIAL weights, dropout off: loss 1e-5
+    V=2048 (vocab-tiled lattice kernels), T=1500, U=80, two utterances (second one with 2U/3 labels), INITIAL weights, dropout off: loss 1e-5
     relative, every parameter gradient 2e-4 of its maximum against the float64 oracle (separable joint: 10 GB per concat copy)."""
     from rnntransducer_amd import RNNTransducer
     V = 2048
@@ -195,7 +207,7 @@ def test_full_model_config5_dims_step_vs_float64_oracle():
     pn = dict(embedding_size=V, hidden_size=640, output_size=640, num_layers=1, rnn_type="lstm", dropout=0.0)
     torch.manual_seed(2)
     model = RNNTransducer(dict(pn), dict(tn), dict(num_classes=V), ARGS)
-    small = make_batch(2, 1500, 80, V, ragged=True, seed=13)
+    small = _two_utterances_equal_frames_ragged_labels(1500, 80, V, seed=13)
     ref_loss, ref_grads = _oracle_step(tn, pn, V, model, small, per_utterance=True, separable=True)
     model = model.cuda().train()
     loss, nll, grads = _hip_step_on_first_rows(model, small, 2)
@@ -243,21 +255,31 @@ def test_lstm_layer_at_the_timed_launch_geometry_vs_torch_float64(name, I, lens)
         x[b, lens[b]:] = 0
     torch.set_num_threads(usable_cores())
     ref_out, ref_dx = _lstm_float64_by_length_class(ref, x, lens, dy)
-    x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
-    y = hip(x_tm, torch.tensor(lens, dtype=torch.int32, device="cuda"))
-    y.backward(dy.transpose(0, 1).contiguous().cuda())
-    torch.cuda.synchronize()
-    err = (y.detach().transpose(0, 1).double().cpu() - ref_out).abs().max().item()
-    assert err < 2e-5, f"{name}: forward err {err}"
-    for b in range(B):
-        assert torch.all(y[lens[b]:, b] == 0)
-    worst = ("", 0.0)
-    for nm, got, want in [("dx", x_tm.grad.transpose(0, 1), ref_dx)] + [(k, getattr(hip, k).grad, p.grad) for k, p in ref.named_parameters()]:
-        scale = max(want.abs().max().item(), 1e-3)
-        e = (got.double().cpu() - want).abs().max().item() / scale
-        worst = max(worst, (nm, e), key=lambda t: t[1])
-        assert e < 2e-4, f"{name} {nm}: {e:.3e} of max {scale:.3e}"
-    print(f"B=32 T=1000 H=512 I={I} ({name}): forward err {err:.2e}, worst gradient {worst[0]} {worst[1]:.2e} of max")
+    from rnntransducer_amd.ops import RaggedPlan
+    lens_dev = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    variants = [("dense", lens_dev)]
+    if min(lens) < T:   # the same launch with the valid-frame table (what training_step builds from the collate's length list)
+        variants.append(("valid-frame table", RaggedPlan(lens, T, "cuda")))
+    for vname, lens_arg in variants:
+        for q in hip.parameters():
+            q.grad = None
+        x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
+        y = hip(x_tm, lens_arg)
+        y.backward(dy.transpose(0, 1).contiguous().cuda())
+        torch.cuda.synchronize()
+        err = (y.detach().transpose(0, 1).double().cpu() - ref_out).abs().max().item()
+        assert err < 2e-5, f"{name} / {vname}: forward err {err}"
+        dx = x_tm.grad.transpose(0, 1).clone()
+        for b in range(B):
+            assert torch.all(y[lens[b]:, b] == 0)
+            dx[b, lens[b]:] = 0   # (gradient w.r.t. padded input frames: unspecified with the table, never consumed)
+        worst = ("", 0.0)
+        for nm, got, want in [("dx", dx, ref_dx)] + [(k, getattr(hip, k).grad, p.grad) for k, p in ref.named_parameters()]:
+            scale = max(want.abs().max().item(), 1e-3)
+            e = (got.double().cpu() - want).abs().max().item() / scale
+            worst = max(worst, (nm, e), key=lambda t: t[1])
+            assert e < 2e-4, f"{name} / {vname} {nm}: {e:.3e} of max {scale:.3e}"
+        print(f"B=32 T=1000 H=512 I={I} ({name}, {vname}): forward err {err:.2e}, worst gradient {worst[0]} {worst[1]:.2e} of max")
 
 
 def test_config3_full_size_joint_loss_never_materialises_btuv():

@@ -72,6 +72,86 @@ def test_lstm_stack_fwd_bwd(B, T, I, H, L, bi):
         close(name, getattr(hip, name).grad, p.grad)
 
 
+@pytest.mark.parametrize("B,T,I,H,L,bi,cell,p", [
+    (32, 40, 80, 512, 2, True, "lstm", 0.0),     # config-2 groups (8 rows), layer-0 width + inner width, half-pair products
+    (8, 150, 128, 512, 1, True, "lstm", 0.0),    # 4-row groups (config-3 geometry)
+    (16, 70, 160, 640, 2, True, "lstm", 0.0),    # 20-unit workgroups, two-barrier backward
+    (32, 80, 256, 256, 2, True, "gru", 0.0),     # GRU: hidden-side gate gradients have their own planes
+    (32, 260, 128, 128, 1, False, "rnn", 0.0),   # Elman, one direction
+    (32, 40, 80, 512, 3, True, "lstm", 0.3),     # dropout between layers: plan vs dense on the same seed
+])
+def test_ragged_plan_skips_padding_without_changing_results(B, T, I, H, L, bi, cell, p):
+    """rnnt_lstm_desc.row_idx (ops.RaggedPlan): the big products run over the valid frames only (operand tiles gathered, results
+    scattered, transposed planes packed along the contraction) and every sync group of the recurrences runs max(lens of its rows)
+    steps.  Against torch float64 on the CPU (dropout 0) with the same tolerances as the dense path, for rows in collate order AND
+    sorted by length; with dropout, against the dense HIP run on the same seed."""
+    from rnntransducer_amd import _lib
+    from rnntransducer_amd.networks.rnn import RNN_CELLS
+    from rnntransducer_amd.ops import LstmStackFn, RaggedPlan
+    torch.manual_seed(B + T + H)
+    D = 2 if bi else 1
+    cell_id = RNN_CELLS[cell].CELL if cell != "rnn" else 2
+    assert _lib.lib().rnnt_hip_lstm_takes_row_idx(T, B, I, H, D, cell_id) == 1   # the table is honoured at this shape, not ignored
+    assert _lib.lib().rnnt_hip_lstm_takes_row_idx(7, 3, 8, 16, D, cell_id) == 0     # (small shapes ignore it and stay dense)
+    ref_cls = {"lstm": nn.LSTM, "gru": nn.GRU, "rnn": nn.RNN}[cell]
+    ref = ref_cls(I, H, L, batch_first=True, bidirectional=bi).double()
+    hip = RNN_CELLS[cell](I, H, L, dropout=p, bidirectional=bi)
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hip = hip.cuda().train()
+    g = torch.Generator().manual_seed(2)
+    for order in ("collate", "sorted"):
+        lens = [T] + torch.randint(max(1, T // 3), T + 1, (B - 1,), generator=g).tolist()
+        if order == "sorted":
+            lens = sorted(lens, reverse=True)
+        x = torch.randn(B, T, I, generator=g)
+        for b in range(B):
+            x[b, lens[b]:] = 0
+        dy = torch.randn(B, T, D * H, generator=g)
+        x_tm = x.transpose(0, 1).contiguous().cuda()
+        dy_tm = dy.transpose(0, 1).contiguous().cuda()
+        lens_dev = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        plan = RaggedPlan(lens, T, "cuda")
+        assert not plan.dense and plan.n_rows == sum(lens)
+
+        def run(lens_arg):
+            for q in hip.parameters():
+                q.grad = None
+            xx = x_tm.clone().requires_grad_(True)
+            pp = p if L > 1 else 0.0
+            y = LstmStackFn.apply(xx, lens_arg, H, L, bi, pp, 4242, hip.CELL, False, *hip.flat_weights())
+            y.backward(dy_tm)
+            torch.cuda.synchronize()
+            return y.detach(), xx.grad, {k: q.grad.clone() for k, q in hip.named_parameters()}
+
+        y_p, dx_p, gr_p = run(plan)
+        for b in range(B):
+            assert torch.all(y_p[lens[b]:, b] == 0)
+        if p > 0:   # same seed, same masks: the dense run is the reference
+            y_d, dx_d, gr_d = run(lens_dev)
+            assert (y_p - y_d).abs().max().item() < 1e-6
+            for b in range(B):   # dx of padded frames is unspecified with a plan (never consumed): compare valid frames
+                assert (dx_p[:lens[b], b] - dx_d[:lens[b], b]).abs().max().item() < 1e-5 * max(1.0, dx_d.abs().max().item())
+            for k in gr_d:
+                assert (gr_p[k] - gr_d[k]).abs().max().item() < 2e-5 * max(gr_d[k].abs().max().item(), 1e-3), k
+            continue
+        ref.zero_grad()
+        ref_out, ref_dx = _oracle(x, lens, ref, dy)
+        err = (y_p.transpose(0, 1).double().cpu() - ref_out).abs().max().item()
+        assert err < FWD_ATOL, f"{order}: forward err {err}"
+
+        def close(name, got, want):
+            scale = max(want.abs().max().item(), 1e-3)
+            e = (got.double().cpu() - want).abs().max().item()
+            assert e < GRAD_RTOL * scale + 1e-6, f"{order} {name}: err {e} scale {scale}"
+
+        dxv = dx_p.transpose(0, 1).clone()
+        for b in range(B):
+            dxv[b, lens[b]:] = 0     # (unspecified with a plan; the oracle has 0 there)
+        close("dx", dxv, ref_dx)
+        for name, q in ref.named_parameters():
+            close(name, gr_p[name], q.grad)
+
+
 def test_lstm_init_matches_torch_rng_stream():
     from rnntransducer_amd.networks.rnn import HipLSTM
     torch.manual_seed(7)

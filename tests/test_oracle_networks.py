@@ -74,24 +74,24 @@ def test_joint_is_separable(golden_dir):
 def test_per_utterance_lstm_equals_the_packed_one():
     """oracle._per_utterance_lstm (used for the float64 checks at config 3 / 5 sizes, where autograd through a PackedSequence is
     O(T^2) on the CPU) is the same function as the packed path the reference fixtures pin: outputs and every gradient to 1e-12,
-    ragged batch, 2 layers, both directions, LSTM and GRU."""
+    2 layers, both directions, LSTM and GRU; ragged batch (one call per utterance) and equal lengths below the padded T (one call)."""
     from oracle import rnnt_oracle as ro
     for cell in (torch.nn.LSTM, torch.nn.GRU):
         torch.manual_seed(3)
         rnn = cell(6, 5, 2, batch_first=True, bidirectional=True).double()
-        x = torch.randn(4, 9, 6, dtype=torch.float64)
-        lens = [9, 4, 7, 1]
-        dy = torch.randn(4, 9, 10, dtype=torch.float64)
-        res = []
-        for fn in (ro._packed_lstm, ro._per_utterance_lstm):
-            rnn.zero_grad()
-            xr = x.clone().requires_grad_(True)
-            y = fn(rnn, xr, lens)
-            y.backward(dy)
-            res.append([y.detach(), xr.grad] + [p.grad.clone() for p in rnn.parameters()])
-        for a, b in zip(*res):
-            assert (a - b).abs().max().item() < 1e-12
-        assert torch.all(res[1][0][1, 4:] == 0) and torch.all(res[1][0][3, 1:] == 0)
+        for lens in ([9, 4, 7, 1], [6, 6, 6, 6]):
+            x = torch.randn(4, 9, 6, dtype=torch.float64)
+            dy = torch.randn(4, 9, 10, dtype=torch.float64)
+            res = []
+            for fn in (ro._packed_lstm, ro._per_utterance_lstm):
+                rnn.zero_grad()
+                xr = x.clone().requires_grad_(True)
+                y = fn(rnn, xr, lens)
+                y.backward(dy)
+                res.append([y.detach(), xr.grad] + [p.grad.clone() for p in rnn.parameters()])
+            for a, b in zip(*res):
+                assert (a - b).abs().max().item() < 1e-12
+            assert torch.all(res[1][0][1, lens[1]:] == 0) and torch.all(res[1][0][3, lens[3]:] == 0)
 
 
 HIDDEN = {
