@@ -315,9 +315,21 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
     const int cur = kt & 1;
     // (measured in one process, tools/gemm_hp_ab.py: issuing the LDS-DMA of waves 4-7 half a tile later than that of their SIMD
     // partners 0-3 is 5 % SLOWER, s_setprio around the MFMA clusters 1 % slower, 256 x 128 tiles with a 3-stage ring 13 % slower)
+#ifndef HP_DBG_NO_DMA   // (diagnostic builds: tools/gemm_hp_bound_probe.sh times the loop without its operand fetch / without its MFMAs)
     if (kt + 1 < nk) stage(cur ^ 1, kt0 + kt + 1);   // lands under this tile's 96 MFMAs
+#endif
     const char* sb = lds + cur * HP_STAGE;
     f16x8 a[4][2], b[2][2];
+#ifdef HP_DBG_NO_LDSREAD   // (diagnostic: operand fragments stay whatever the registers hold — the MFMA pipe alone)
+    auto load_a = [&](int mq) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(a[i][0]), "+v"(a[i][1])); }
+    };
+    auto load_b = [&](int nq) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(b[j][0]), "+v"(b[j][1])); }
+    };
+#else
     auto load_a = [&](int mq) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -332,6 +344,7 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
         b[j][1] = *reinterpret_cast<const f16x8*>(sb + ((b_base ^ 64) + (2 * nq + j) * 2048));
       }
     };
+#endif
     auto mma = [&](int mq, int nq) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -344,12 +357,16 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
           acc[4 * mq + i][2 * nq + j] = c;
         }
     };
+#ifndef HP_DBG_NO_MFMA
     load_a(0); load_b(0); mma(0, 0);
     load_b(1); mma(0, 1);
     load_a(1); mma(1, 1);
     load_b(0); mma(1, 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);  // keep all 96 MFMAs in front of the wait (hipcc otherwise sinks half of them behind the barrier)
+#ifndef HP_DBG_NO_BARRIER
     __syncthreads();   // drains the LDS-DMA of the next stage (vmcnt(0)) and fences this stage's reads
+#endif
   }
 
   // epilogue: D block (i, j): lane -> rows 4*(lane>>4) + reg, column lane&15
