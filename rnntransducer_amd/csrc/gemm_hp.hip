@@ -25,6 +25,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace rnnt {
 namespace {
 
@@ -308,6 +310,110 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
   const int kt0 = z * p.kt_per_split;
   const int nk = min(p.nkt - kt0, p.kt_per_split);
 
+#ifdef HP_PIPE
+  // Software-pipelined main loop — build variant only (-DHP_PIPE=1), NOT the default: it measured within 1 % of the plain loop below
+  // (profiles/r03_gemm_hp_bound_probe.txt: dX 610 vs 617 us, proj 755 vs 741, dW 589 vs 592).  The probe variants of the same file
+  // say why: the MFMAs alone run at 0.83 of the nominal f16 peak (power-limited clock); with the operand fragments read from LDS at
+  // 0.61-0.63 WHETHER OR NOT the reads are issued a quarter tile ahead (so it is not exposed LDS latency: every ds_read_b128 costs the
+  // SIMD about 20 cycles of MFMA issue while its 1 KB lands in the register file), and the operand fetch alone (LDS-DMA, no MFMA) takes
+  // 0.72 of the full kernel's time at 77 % L2 hits (one 64 KB round trip per K-tile and CU: a 2-stage ring cannot keep more in flight).
+  // Every ds_read_b128 is issued at least 12 MFMAs (usually a whole quarter = 24) ahead of its first use:
+  //   quarter  operands (A half, B half)   loads issued during it
+  //   Q0       a(mq 0), set0 = b(nq 0)     set1 <- b(nq 1)
+  //   Q1       a(mq 0), set1               a[i] <- A(mq 1) block i, as soon as block i's MFMAs are issued
+  //   Q2       a(mq 1), set1               set0 <- b(nq 0) again;  then vmcnt(0) + lgkmcnt(0) + BARRIER (the only one per K-tile)
+  //   Q3       a(mq 1), set0               LDS-DMA of K-tile kt + 2 into THIS tile's (now fully read) stage;  set1 <- next tile's b(nq 0),
+  //                                        a[i] <- next tile's A(mq 0) block i — from the other stage, whose DMA the barrier waited for
+  // The two B register sets swap roles every K-tile (the loop body is instantiated for both parities).  Every accumulator still sees
+  // its K-tiles and, inside one, its three products in the same order: results are bitwise those of the plain loop (HP_NO_PIPE).
+  f16x8 a[4][2], bs[2][2][2];
+  auto ld_a = [&](const char* sb, int mq, int i) {
+    a[i][0] = *reinterpret_cast<const f16x8*>(sb + (a_base + (4 * mq + i) * 2048));
+    a[i][1] = *reinterpret_cast<const f16x8*>(sb + ((a_base ^ 64) + (4 * mq + i) * 2048));
+  };
+  auto ld_b = [&](int set, const char* sb, int nq) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bs[set][j][0] = *reinterpret_cast<const f16x8*>(sb + (b_base + (2 * nq + j) * 2048));
+      bs[set][j][1] = *reinterpret_cast<const f16x8*>(sb + ((b_base ^ 64) + (2 * nq + j) * 2048));
+    }
+  };
+  // blocks i0, i0 + 1 of A half mq against B half nq (register set `set`): 12 MFMAs, four independent accumulators between dependent ones
+  auto mma2 = [&](int mq, int nq, int set, int i0) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = i0; i < i0 + 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 c = acc[4 * mq + i][2 * nq + j];
+          if (t == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], bs[set][j][0], c, 0, 0, 0);   // smallest terms first
+          else if (t == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], bs[set][j][1], c, 0, 0, 0);
+          else c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], bs[set][j][0], c, 0, 0, 0);
+          acc[4 * mq + i][2 * nq + j] = c;
+        }
+  };
+#define HP_PIN() __builtin_amdgcn_sched_barrier(0)   /* nothing moves across: the loads stay where the table above puts them */
+
+  stage(0, kt0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nk > 1) stage(1, kt0 + 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ld_a(lds, 0, i);
+  ld_b(0, lds, 0);
+  HP_PIN();
+
+  auto ktile = [&](auto parity, const int kt) {
+    constexpr int S0 = decltype(parity)::value, S1 = S0 ^ 1;   // B register sets: S0 holds nq 0 on entry
+    const char* sb = lds + S0 * HP_STAGE;                       // stage of this K-tile: kt0-relative parity == S0 by construction
+    const char* nb = lds + S1 * HP_STAGE;
+    // Q0  (the loads of set1 sit BEHIND the first 12 MFMAs: at the loop head hipcc waits with lgkmcnt(0) — it cannot count what the
+    //      previous iteration left in flight — and loads issued in front of that wait would be waited for at once)
+    mma2(0, 0, S0, 0);
+    HP_PIN();            // (blocks 2, 3 of A arrived 12 MFMAs later than blocks 0, 1: their MFMAs stay behind those of 0, 1)
+    ld_b(S1, sb, 1);
+    HP_PIN();
+    mma2(0, 0, S0, 2);
+    HP_PIN();
+    // Q1
+    mma2(0, 1, S1, 0);
+    HP_PIN();
+    ld_a(sb, 1, 0); ld_a(sb, 1, 1);
+    HP_PIN();
+    mma2(0, 1, S1, 2);
+    HP_PIN();
+    ld_a(sb, 1, 2); ld_a(sb, 1, 3);
+    ld_b(S0, sb, 0);
+    HP_PIN();
+    // Q2
+    mma2(1, 1, S1, 0);
+    HP_PIN();
+    mma2(1, 1, S1, 2);
+    HP_PIN();
+    __syncthreads();   // vmcnt(0): the LDS-DMA of K-tile kt + 1 has landed; lgkmcnt(0): every read of this stage is done
+    HP_PIN();
+#ifndef HP_DBG_NO_DMA
+    if (kt + 2 < nk) stage(S0, kt0 + kt + 2);
+#endif
+    // Q3 (+ the first fragments of K-tile kt + 1; behind the last K-tile these read stale LDS into dead registers)
+    ld_b(S1, nb, 0);
+    HP_PIN();
+    mma2(1, 0, S0, 0);
+    HP_PIN();
+    ld_a(nb, 0, 0); ld_a(nb, 0, 1);
+    HP_PIN();
+    mma2(1, 0, S0, 2);
+    HP_PIN();
+    ld_a(nb, 0, 2); ld_a(nb, 0, 3);
+    HP_PIN();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) ktile(std::integral_constant<int, 1>{}, kt + 1);
+  }
+#undef HP_PIN
+#else
   stage(0, kt0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -369,6 +475,7 @@ __device__ __forceinline__ void hp_tile256(const HpGemmK& p, const int bid, cons
 #endif
   }
 
+#endif
   // epilogue: D block (i, j): lane -> rows 4*(lane>>4) + reg, column lane&15
   const int mode = p.splits > 1 ? 0 : ((p.flags & RNNT_GEMM_ACCUM) ? 2 : 1);  // uniform: slab | store | accumulate
   float* slab = p.splits > 1 ? p.slab + (long)z * p.M * p.N : nullptr;
