@@ -17,6 +17,8 @@
 //   grad_dense_kernel                 : warp-transducer-shaped d/d logits for rnnt_hip_loss_from_logits_*
 #include "common.hpp"
 
+#include <stdlib.h>
+
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
@@ -96,6 +98,85 @@ __global__ void __launch_bounds__(256) lse_sep_kernel(const float* __restrict__ 
       e = Ab[(long)t * a_st + y] + Cb[(long)u * c_su + y] + bias[y] - lse;
     }
     emit[o] = e;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// per-cell log-sum-exp for LARGE vocabularies (V >= 256: BASELINE configs[4], V = 2048).  Same outputs as lse_sep_kernel.
+// lse_sep_kernel spends its time in ocml expf (~20 VALU instructions per element) and in two LDS reads per element; here a thread
+// owns 4 label positions of one frame (every A value read from LDS feeds 4 cells), the chunk is staged pre-multiplied by log2(e) and
+// the sum runs on v_exp_f32 (2^x): per element one add for the chunk maximum, then add + sub + v_exp_f32 + add.
+// grid (ceil(T/32), ceil(U1/32), B), 256 threads = 32 t x 8 groups of 4 u.
+// ------------------------------------------------------------------------------------------------
+constexpr int LSV_UR = 4, LSV_UT = 8 * LSV_UR, LSV_VC = 128;
+constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
+
+__global__ void __launch_bounds__(256) lse_sepv_kernel(const float* __restrict__ A, const float* __restrict__ C,
+                                                       const float* __restrict__ bias, const int* __restrict__ labels,
+                                                       int T, int U1, int V, int blank, long a_sb, long a_st,
+                                                       long c_sb, long c_su, float* __restrict__ blk,
+                                                       float* __restrict__ emit) {
+  __shared__ float As[TT][LSV_VC + 1];
+  __shared__ float Cs[LSV_UT][LSV_VC + 1];
+  const int b = blockIdx.z, t0 = blockIdx.x * TT, u0 = blockIdx.y * LSV_UT;
+  const int tid = threadIdx.x, tl = tid & 31, ug = tid >> 5;
+  const int t = t0 + tl;
+  const float* Ab = A + (long)b * a_sb;
+  const float* Cb = C + (long)b * c_sb;
+
+  float m[LSV_UR], s[LSV_UR];   // running maximum (log2 domain) and sum of 2^(x - m)
+#pragma unroll
+  for (int r = 0; r < LSV_UR; ++r) { m[r] = -__builtin_huge_valf(); s[r] = 0.f; }
+  for (int v0 = 0; v0 < V; v0 += LSV_VC) {
+    const int vc = min(LSV_VC, V - v0);
+    __syncthreads();
+    for (int i = tid; i < TT * LSV_VC; i += 256) {
+      const int r = i / LSV_VC, c = i % LSV_VC;
+      As[r][c] = (t0 + r < T && c < vc) ? Ab[(long)(t0 + r) * a_st + v0 + c] * LOG2E_F : 0.f;
+    }
+    for (int i = tid; i < LSV_UT * LSV_VC; i += 256) {
+      const int r = i / LSV_VC, c = i % LSV_VC;
+      Cs[r][c] = (u0 + r < U1 && c < vc) ? (Cb[(long)(u0 + r) * c_su + v0 + c] + bias[v0 + c]) * LOG2E_F : 0.f;
+    }
+    __syncthreads();
+    float cm[LSV_UR];
+#pragma unroll
+    for (int r = 0; r < LSV_UR; ++r) cm[r] = -__builtin_huge_valf();
+    for (int c = 0; c < vc; ++c) {
+      const float a = As[tl][c];
+#pragma unroll
+      for (int r = 0; r < LSV_UR; ++r) cm[r] = fmaxf(cm[r], a + Cs[ug * LSV_UR + r][c]);
+    }
+    float nm[LSV_UR], cs[LSV_UR];
+#pragma unroll
+    for (int r = 0; r < LSV_UR; ++r) { nm[r] = fmaxf(m[r], cm[r]); cs[r] = 0.f; }
+    for (int c = 0; c < vc; ++c) {
+      const float a = As[tl][c];
+#pragma unroll
+      for (int r = 0; r < LSV_UR; ++r) cs[r] += __builtin_amdgcn_exp2f(a + Cs[ug * LSV_UR + r][c] - nm[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < LSV_UR; ++r) {
+      s[r] = s[r] * __builtin_amdgcn_exp2f(m[r] - nm[r]) + cs[r];   // (first chunk: s = 0, 2^-inf = 0)
+      m[r] = nm[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LSV_UR; ++r) {
+    const int u = u0 + ug * LSV_UR + r;
+    if (t < T && u < U1) {
+      const float lse = (m[r] + __builtin_amdgcn_logf(s[r])) * LN2_F;   // v_log_f32 = log2
+      const long o = ((long)b * U1 + u) * T + t;
+      const float zb = Ab[(long)t * a_st + blank] + Cb[(long)u * c_su + blank] + bias[blank];
+      blk[o] = zb - lse;
+      float e = 0.f;
+      if (u < U1 - 1) {
+        const int y = labels[(long)b * (U1 - 1) + u];
+        e = Ab[(long)t * a_st + y] + Cb[(long)u * c_su + y] + bias[y] - lse;
+      }
+      emit[o] = e;
+    }
   }
 }
 
@@ -332,13 +413,13 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
 
   for (int i = tid; i < U1; i += 256) ys[i] = (i < U1 - 1) ? labels[(long)b * (U1 - 1) + i] : -1;
   for (int i = tid; i < TT * U1; i += 256) {
-    const int tl = i / U1, u = i % U1, t = t0 + tl;
+    const int u = i / TT, tl = i % TT, t = t0 + tl;   // consecutive threads -> consecutive frames: alpha / beta / blk / emit rows are read coalesced
     CellS c = {0.f, 0.f, 0.f, 0.f};
     if (t < Tb && u <= Ub) {
       const float zb = Ab[(long)t * a_st + blank] + Cb[(long)u * c_su + blank] + bias[blank];
       c = cell_scalars(blk, emit, alpha, beta, rowbase, T, t, u, Tb, Ub, logZ, zb);
     }
-    cells[i] = c;
+    cells[tl * U1 + u] = c;
   }
 
   for (int v0 = 0; v0 < V; v0 += 64) {
@@ -415,6 +496,133 @@ __global__ void __launch_bounds__(256) grad_sep_kernel(const float* __restrict__
       const int u = i >> 6, c = i & 63;
       if (v0 + c < V) dCtile[(long)u * V + v0 + c] = dCs[i];
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// lattice gradient for LARGE vocabularies (V >= 256).  Same outputs as grad_sep_kernel (dA, per-tile dC slabs for reduce_dc_kernel).
+// grad_sep_kernel keeps the whole vocabulary loop inside one workgroup per (utterance, 32-frame tile): 82 KB of LDS (one workgroup of
+// 4 waves per CU), four barriers and an LDS merge of the waves' dC sums per 8 label positions and 64-entry vocabulary chunk — at
+// V = 2048 it ran 5.6 ms for 4 G elements (profiles/r02_final_bench_c5.log), 7x off the v_exp_f32 rate.  Here the vocabulary is a
+// GRID dimension and a LANE owns one vocabulary entry v for the whole tile: dA[t][v] (sum over u) and dC[u][v] (sum over the tile's
+// frames) are both plain register sums of that lane — no cross-lane or cross-wave merge, no barrier after the cell table is built,
+// LDS holds the per-cell scalars only (read as broadcasts).  The blank / label corrections leave the inner loop: the one wave whose
+// 64 entries contain the blank (a label) subtracts them in a second, exp-free pass.  Arithmetic per element: two adds, v_exp_f32
+// (2^x on operands pre-multiplied by log2 e), one multiply, two accumulations.
+// grid (ceil(T/32), ceil(V / (64 NW)), B), 64 NW threads; dynamic LDS: cells[TT][U1] (CellS, lse in the log2 domain) | ys[U1]
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 3) grad_sepv_kernel(const float* __restrict__ A, const float* __restrict__ C,
+                                                            const float* __restrict__ bias, const int* __restrict__ labels,
+                                                            const int* __restrict__ t_lens, const int* __restrict__ u_lens,
+                                                            const float* __restrict__ blk, const float* __restrict__ emit,
+                                                            const double* __restrict__ alpha, const double* __restrict__ beta,
+                                                            const double* __restrict__ ll, int T, int U1, int V, int blank,
+                                                            long a_sb, long a_st, long c_sb, long c_su, float gscale_in,
+                                                            const float* __restrict__ gvec, int gvec_stride,
+                                                            float* __restrict__ dA, float* __restrict__ dCp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* wl = reinterpret_cast<float2*>(smem);          // [TT][U1] {occupancy w, row lse * log2 e}: what the inner loop reads (8-byte broadcasts)
+  float2* cbe = wl + TT * U1;                            // [TT][U1] {P(blank transition), P(label transition)}: the correction pass
+  int* ys = reinterpret_cast<int*>(cbe + TT * U1);
+
+  const int b = blockIdx.z, tile = blockIdx.x, t0 = tile * TT, ntiles = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vw0 = (blockIdx.y * NW + wave) * 64;     // first vocabulary entry of this wave
+  const int v = vw0 + lane;
+  const bool vok = v < V;
+  const int Tb = t_lens[b], Ub = u_lens[b];
+  const long rowbase = (long)b * U1 * T;
+  const double logZ = ll[b];
+  const float gscale = gvec ? gscale_in * gvec[(long)b * gvec_stride] : gscale_in;
+  const float* Ab = A + (long)b * a_sb;
+  const float* Cb = C + (long)b * c_sb;
+  float* dCtile = dCp + ((long)b * ntiles + tile) * U1 * V;
+  const int nf = max(0, min(TT, Tb - t0));            // valid frames of this tile (uniform)
+
+  for (int i = tid; i < U1; i += 64 * NW) ys[i] = (i < U1 - 1) ? labels[(long)b * (U1 - 1) + i] : -1;
+  for (int i = tid; i < TT * U1; i += 64 * NW) {
+    const int u = i / TT, tl = i % TT, t = t0 + tl;   // consecutive threads -> consecutive frames: alpha / beta / blk / emit rows are read coalesced
+    CellS c = {0.f, 0.f, 0.f, 0.f};
+    if (t < Tb && u <= Ub) {
+      const float zb = Ab[(long)t * a_st + blank] + Cb[(long)u * c_su + blank] + bias[blank];
+      c = cell_scalars(blk, emit, alpha, beta, rowbase, T, t, u, Tb, Ub, logZ, zb);
+    }
+    // cells outside the utterance's lattice: w = 0 and an lse that sends 2^(x - lse) to 0, so the inner loop needs no per-cell test
+    const bool in = t < Tb && u <= Ub;
+    wl[tl * U1 + u] = make_float2(c.w, in ? c.lse * LOG2E_F : 1e30f);
+    cbe[tl * U1 + u] = make_float2(c.cb, c.ce);
+  }
+  __syncthreads();
+  if (vw0 >= V) return;   // (whole wave beyond the vocabulary: nothing to do, and no barrier follows)
+
+  float a2[TT], accA[TT];
+#pragma unroll
+  for (int tl = 0; tl < TT; ++tl) {
+    a2[tl] = (tl < nf && vok) ? Ab[(long)(t0 + tl) * a_st + v] * LOG2E_F : 0.f;
+    accA[tl] = 0.f;
+  }
+  const float bias_v = vok ? bias[v] : 0.f;
+  const bool has_blank = blank >= vw0 && blank < vw0 + 64;   // uniform over the wave
+  constexpr int UC = 8;
+  for (int u0 = 0; u0 < U1; u0 += UC) {
+    float accC[UC], cs2[UC];
+#pragma unroll
+    for (int j = 0; j < UC; ++j) {
+      const int u = min(u0 + j, U1 - 1);
+      accC[j] = 0.f;
+      cs2[j] = vok ? (Cb[(long)u * c_su + v] + bias_v) * LOG2E_F : 0.f;
+    }
+    if (u0 <= Ub) {
+      // branch-free over the whole 32 x 8 block (cells outside the lattice contribute exact zeros; label positions beyond U1 - 1
+      // re-read the last row's table entries, whose sums are not stored): the 256 table reads and v_exp_f32 pipeline freely
+#pragma unroll
+      for (int tl = 0; tl < TT; ++tl) {
+#pragma unroll
+        for (int j = 0; j < UC; ++j) {
+          const float2 c = wl[tl * U1 + min(u0 + j, U1 - 1)];
+          // the softmax probability (<= 1: the exponent is z - lse <= 0) times the cell's occupancy
+          const float g = c.x * __builtin_amdgcn_exp2f(a2[tl] + cs2[j] - c.y);
+          accA[tl] += (u0 + j < U1) ? g : 0.f;   // (a -1e30 entry in cs2 instead of this select: hipcc then spilled — 3.3 instead of 2.1 ms)
+          accC[j] += g;
+        }
+        // two frames (16 table reads) per scheduling region: without the fence hipcc hoists all 256 reads of the block to its top
+        // (288 registers: one wave per SIMD; with a register cap: spills), with it 131 registers and three waves per SIMD cover the reads
+        if (tl & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      // corrections: - P(blank transition) on the blank entry, - P(label transition) on the label's entry
+#pragma unroll
+      for (int j = 0; j < UC; ++j) {
+        const int u = u0 + j;
+        if (u <= Ub) {
+          const int y = ys[u];
+          const bool mine = y >= vw0 && y < vw0 + 64;   // uniform
+          if (mine || has_blank) {
+#pragma unroll
+            for (int tl = 0; tl < TT; ++tl) {
+              if (tl < nf) {
+                const float2 c = cbe[tl * U1 + u];
+                const float corr = (v == blank ? c.x : 0.f) + (v == y ? c.y : 0.f);
+                accA[tl] -= corr;
+                accC[j] -= corr;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (vok) {
+#pragma unroll
+      for (int j = 0; j < UC; ++j)
+        if (u0 + j < U1) dCtile[(long)(u0 + j) * V + v] = accC[j];   // rows beyond Ub: zeros (reduce_dc_kernel sums every row)
+    }
+  }
+  if (vok) {
+#pragma unroll
+    for (int tl = 0; tl < TT; ++tl)
+      if (t0 + tl < T) dA[(long)b * a_sb + (long)(t0 + tl) * a_st + v] = accA[tl] * gscale;
   }
 }
 
@@ -547,19 +755,37 @@ int launch_alphabeta(const LossWs& w, const int* t_lens, const int* u_lens, int 
 
 using namespace rnnt;
 
+// vocabularies from 256 entries take the lane-per-entry kernels (lse_sepv_kernel, grad_sepv_kernel); RNNT_LOSS_SMALLV_KERNELS=1 keeps
+// the round-1 kernels everywhere, RNNT_LOSS_LARGEV_KERNELS=1 takes the new ones for every V (A/B and tests)
+static bool large_vocab(int V) {
+  if (getenv("RNNT_LOSS_SMALLV_KERNELS")) return false;
+  return V >= 256 || getenv("RNNT_LOSS_LARGEV_KERNELS") != nullptr;
+}
+
 static int launch_grad_sep(const LossWs& w, const float* A, int64_t a_sb, int64_t a_st, const float* C, int64_t c_sb, int64_t c_su,
                            const float* bias, const int32_t* labels, const int32_t* t_lens, const int32_t* u_lens, int32_t B,
                            int32_t T, int32_t U1, int32_t V, int32_t blank, float gscale, const float* gvec, int gvec_stride, float* dA,
                            float* dC, hipStream_t s) {
   const int ntiles = (int)ceil_div(T, TT);
   const double cells = (double)B * T * U1;
-  const size_t lds = (size_t)TT * U1 * sizeof(CellS) + (size_t)U1 * 64 * 4 * 2 + (size_t)U1 * 4;
-  RNNT_CHECK_ARG(lds <= 160 * 1024, "joint_loss: U+1 = %d needs %zu B of LDS (> 160 KiB)", U1, lds);
-  if (lds > 64 * 1024)
-    RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)grad_sep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope prof(RNNT_K_LATGRAD, 4.0 * 2.0 * ((double)B * T * V + (double)B * U1 * V) + 24.0 * cells, s);
-  hipLaunchKernelGGL(grad_sep_kernel, dim3(ntiles, B), dim3(256), lds, s, A, C, bias, labels, t_lens, u_lens, w.blk,
-                     w.emit, w.alpha, w.beta, w.ll, T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, gscale, gvec, gvec_stride, dA, w.dCp);
+  if (large_vocab(V)) {   // a lane per vocabulary entry, the vocabulary a grid dimension (grad_sepv_kernel)
+    const size_t lds = (size_t)TT * U1 * sizeof(CellS) + (size_t)U1 * 4;
+    RNNT_CHECK_ARG(lds <= 160 * 1024, "joint_loss: U+1 = %d needs %zu B of LDS (> 160 KiB)", U1, lds);
+    constexpr int NW = 4;   // 256 vocabulary entries per workgroup (8 waves per workgroup measured slower: 5.2 vs 4.6 ms at config 5)
+    if (lds > 64 * 1024)
+      RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)grad_sepv_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(grad_sepv_kernel<NW>, dim3(ntiles, (unsigned)ceil_div(V, 64 * NW), B), dim3(64 * NW), lds, s, A, C, bias, labels, t_lens,
+                       u_lens, w.blk, w.emit, w.alpha, w.beta, w.ll, T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, gscale, gvec,
+                       gvec_stride, dA, w.dCp);
+  } else {
+    const size_t lds = (size_t)TT * U1 * sizeof(CellS) + (size_t)U1 * 64 * 4 * 2 + (size_t)U1 * 4;
+    RNNT_CHECK_ARG(lds <= 160 * 1024, "joint_loss: U+1 = %d needs %zu B of LDS (> 160 KiB)", U1, lds);
+    if (lds > 64 * 1024)
+      RNNT_CHECK_HIP(hipFuncSetAttribute((const void*)grad_sep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(grad_sep_kernel, dim3(ntiles, B), dim3(256), lds, s, A, C, bias, labels, t_lens, u_lens, w.blk,
+                       w.emit, w.alpha, w.beta, w.ll, T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, gscale, gvec, gvec_stride, dA, w.dCp);
+  }
   RNNT_CHECK_LAUNCH();
   const long per_b = (long)U1 * V;
   hipLaunchKernelGGL(reduce_dc_kernel, dim3((unsigned)ceil_div(per_b, 256), B), dim3(256), 0, s, w.dCp, ntiles, per_b,
@@ -589,8 +815,12 @@ extern "C" int rnnt_hip_joint_loss_fwd_bwd(const float* A, int64_t a_sb, int64_t
   const double cells = (double)B * T * U1;
   {
   ProfScope prof(RNNT_K_LSE, 4.0 * ((double)B * T * V + (double)B * U1 * V) + 8.0 * cells, s);
-  hipLaunchKernelGGL(lse_sep_kernel, dim3(ntiles, (unsigned)ceil_div(U1, LSE_UT), B), dim3(256), 0, s, A, C, bias, labels,
-                     T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, w.blk, w.emit);
+  if (large_vocab(V))
+    hipLaunchKernelGGL(lse_sepv_kernel, dim3(ntiles, (unsigned)ceil_div(U1, LSV_UT), B), dim3(256), 0, s, A, C, bias, labels,
+                       T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, w.blk, w.emit);
+  else
+    hipLaunchKernelGGL(lse_sep_kernel, dim3(ntiles, (unsigned)ceil_div(U1, LSE_UT), B), dim3(256), 0, s, A, C, bias, labels,
+                       T, U1, V, blank, (long)a_sb, (long)a_st, (long)c_sb, (long)c_su, w.blk, w.emit);
   }
   RNNT_CHECK_LAUNCH();
   if (int rc = launch_alphabeta(w, t_lens, u_lens, B, T, U1, s)) return rc;
