@@ -235,6 +235,13 @@ __device__ __forceinline__ double shfl_down1(double x, int lane) {
 }
 
 constexpr int PF = 8;  // rows of blk/emit in flight per lane (register ring)
+constexpr int AB_RSRC = 0x00027000, AB_OOB = 0x7ffffff0;
+// The sweep is a chain of ~T + U dependent steps (one anti-diagonal each).  Every memory operation of the loop goes through a buffer
+// resource with an out-of-range offset for lanes / steps that have no cell (loads return 0, stores are dropped): the loop body has NO
+// branch around a memory operation, so hipcc counts how many younger operations may stay in flight when it waits for a ring slot
+// (`s_waitcnt vmcnt(n)`, n > 0).  With the loads and stores inside `if (cell exists)` branches — the round-1 form — it could not, fell
+// back to vmcnt(0) after every step and each step waited out the loads it had just issued for 8 steps later: 950 cycles per step at
+// config 2 (0.41 ms per training step for a 1 040-step chain) against the ~300 the arithmetic takes.
 template <int K>
 __global__ void __launch_bounds__(64) alphabeta_kernel(const float* __restrict__ blk, const float* __restrict__ emit,
                                                        const int* __restrict__ t_lens, const int* __restrict__ u_lens,
@@ -246,30 +253,40 @@ __global__ void __launch_bounds__(64) alphabeta_kernel(const float* __restrict__
   const int ulo = lane * K;
   const int lastlane = Ub / K;
   const int nsteps = Tb + lastlane;
+  const int cells = U1 * T;
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blk + rowbase), 0, cells * 4, AB_RSRC);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(emit + rowbase), 0, cells * 4, AB_RSRC);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((which == 0 ? alpha : beta) + rowbase, 0, cells * 8, AB_RSRC);
+  auto cell = [&](int u, int t) -> int { return (t >= 0 && t < Tb && u <= Ub) ? u * T + t : -1; };
+  auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int c) -> float {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, c >= 0 ? c * 4 : AB_OOB, 0, 0));
+  };
+  auto st = [&](double v, int c) {
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), ro, c >= 0 ? c * 8 : AB_OOB, 0, 0);
+  };
+  const int nrounds = (nsteps + PF - 1) / PF;   // steps beyond nsteps touch no cell (every lane is past its last row)
+  double llv = NEG_INF;
 
   if (which == 0) {
     double down[K];  // alpha[t-1][u] + blk[t-1][u]
 #pragma unroll
     for (int k = 0; k < K; ++k) down[k] = NEG_INF;
     double eout = NEG_INF;  // alpha[t][uhi] + emit[t][uhi] of this lane's last cell at its current row
-    // The sweep is a chain of ~T dependent steps; a row's blk/emit values are fetched PF steps ahead into a register ring
-    // (one step ahead left every step waiting out a global-load latency: 535 ns per step at c2)
+    // a row's blk/emit values are fetched PF steps ahead into a register ring
     float pb[PF][K], pe[PF][K];
 #pragma unroll
     for (int j = 0; j < PF; ++j)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int u = ulo + k, t = j - lane;
-        const bool ok = (t >= 0 && t < Tb && u <= Ub);
-        pb[j][k] = ok ? blk[rowbase + (long)u * T + t] : 0.f;
-        pe[j][k] = ok ? emit[rowbase + (long)u * T + t] : 0.f;
+        const int c = cell(ulo + k, j - lane);
+        pb[j][k] = ld(rb, c);
+        pe[j][k] = ld(re, c);
       }
-    for (int n0 = 0; n0 < nsteps; n0 += PF) {
+    for (int r = 0; r < nrounds; ++r) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
-        const int n = n0 + j;
-        if (n >= nsteps) break;
-        const int t = n - lane;
+        const int t = r * PF + j - lane;
         const double carry = shfl_up1(eout, lane);
         float cb[K], ce[K];
 #pragma unroll
@@ -277,28 +294,27 @@ __global__ void __launch_bounds__(64) alphabeta_kernel(const float* __restrict__
         // refill this ring slot with the row of step n + PF
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const int u = ulo + k, tn = t + PF;
-          const bool ok = (tn >= 0 && tn < Tb && u <= Ub);
-          pb[j][k] = ok ? blk[rowbase + (long)u * T + tn] : 0.f;
-          pe[j][k] = ok ? emit[rowbase + (long)u * T + tn] : 0.f;
+          const int c = cell(ulo + k, t + PF);
+          pb[j][k] = ld(rb, c);
+          pe[j][k] = ld(re, c);
         }
-        if (t >= 0 && t < Tb) {
-          double left = carry;
+        const bool row = t >= 0 && t < Tb;
+        double left = carry;
 #pragma unroll
-          for (int k = 0; k < K; ++k) {
-            const int u = ulo + k;
-            if (u <= Ub) {
-              const double a = (t == 0 && u == 0) ? 0.0 : logaddexp_d(down[k], left);
-              alpha[rowbase + (long)u * T + t] = a;
-              down[k] = a + (double)cb[k];
-              left = (u < Ub) ? a + (double)ce[k] : NEG_INF;
-              if (t == Tb - 1 && u == Ub) ll[b] = down[k];
-            }
-          }
-          eout = left;
+        for (int k = 0; k < K; ++k) {
+          const int u = ulo + k;
+          const bool ok = row && u <= Ub;
+          const double a = (t == 0 && u == 0) ? 0.0 : logaddexp_d(down[k], left);
+          st(a, ok ? u * T + t : -1);
+          const double nd = a + (double)cb[k];
+          down[k] = ok ? nd : down[k];
+          left = ok ? ((u < Ub) ? a + (double)ce[k] : NEG_INF) : left;
+          llv = (ok && t == Tb - 1 && u == Ub) ? nd : llv;
         }
+        eout = row ? left : eout;
       }
     }
+    if (lane == lastlane) ll[b] = llv;   // the lane that owns cell (Tb - 1, Ub)
   } else {
     double down[K];  // beta[t+1][u]
 #pragma unroll
@@ -310,52 +326,42 @@ __global__ void __launch_bounds__(64) alphabeta_kernel(const float* __restrict__
     for (int j = 0; j < PF; ++j)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int u = ulo + k, t = Tb - 1 - (j - (lastlane - lane));
-        const bool ok = (t >= 0 && t < Tb && u <= Ub);
-        pb[j][k] = ok ? blk[rowbase + (long)u * T + t] : 0.f;
-        pe[j][k] = ok ? emit[rowbase + (long)u * T + t] : 0.f;
+        const int c = cell(ulo + k, Tb - 1 - (j - (lastlane - lane)));
+        pb[j][k] = ld(rb, c);
+        pe[j][k] = ld(re, c);
       }
-    for (int n0 = 0; n0 < nsteps; n0 += PF) {
+    for (int r = 0; r < nrounds; ++r) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
-        const int n = n0 + j;
-        if (n >= nsteps) break;
-        const int t = Tb - 1 - (n - (lastlane - lane));
+        const int t = Tb - 1 - (r * PF + j - (lastlane - lane));
         const double carry = shfl_down1(bout, lane);  // beta[t][(lane+1)*K]
         float cb[K], ce[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) { cb[k] = pb[j][k]; ce[k] = pe[j][k]; }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const int u = ulo + k, tn = t - PF;
-          const bool ok = (tn >= 0 && tn < Tb && u <= Ub);
-          pb[j][k] = ok ? blk[rowbase + (long)u * T + tn] : 0.f;
-          pe[j][k] = ok ? emit[rowbase + (long)u * T + tn] : 0.f;
+          const int c = cell(ulo + k, t - PF);
+          pb[j][k] = ld(rb, c);
+          pe[j][k] = ld(re, c);
         }
-        if (t >= 0 && t < Tb && lane <= lastlane) {
-          double right = carry;  // beta[t][u+1]
+        const bool row = t >= 0 && t < Tb && lane <= lastlane;
+        double right = carry;  // beta[t][u+1]
 #pragma unroll
-          for (int k = K - 1; k >= 0; --k) {
-            const int u = ulo + k;
-            if (u <= Ub) {
-              double v;
-              if (t == Tb - 1 && u == Ub) {
-                v = (double)cb[k];
-              } else {
-                const double ne = down[k] == NEG_INF ? NEG_INF : down[k] + (double)cb[k];
-                const double em = (u < Ub && right != NEG_INF) ? right + (double)ce[k] : NEG_INF;
-                v = logaddexp_d(ne, em);
-              }
-              beta[rowbase + (long)u * T + t] = v;
-              down[k] = v;
-              right = v;
-              if (t == 0 && u == 0) ll[gridDim.x + b] = v;
-            }
-          }
-          bout = right;
+        for (int k = K - 1; k >= 0; --k) {
+          const int u = ulo + k;
+          const bool ok = row && u <= Ub;
+          const double ne = down[k] == NEG_INF ? NEG_INF : down[k] + (double)cb[k];
+          const double em = (u < Ub && right != NEG_INF) ? right + (double)ce[k] : NEG_INF;
+          const double v = (t == Tb - 1 && u == Ub) ? (double)cb[k] : logaddexp_d(ne, em);
+          st(v, ok ? u * T + t : -1);
+          down[k] = ok ? v : down[k];
+          right = ok ? v : right;
+          llv = (ok && t == 0 && u == 0) ? v : llv;
         }
+        bout = row ? right : bout;
       }
     }
+    if (lane == 0) ll[gridDim.x + b] = llv;   // the lane that owns cell (0, 0)
   }
 }
 
