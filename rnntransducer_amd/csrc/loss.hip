@@ -376,17 +376,20 @@ __device__ __forceinline__ CellS cell_scalars(const float* __restrict__ blk, con
                                               const double* __restrict__ alpha, const double* __restrict__ beta,
                                               long rowbase, int T, int t, int u, int Tb, int Ub, double logZ,
                                               float zblank) {
+  // (t, u) must be a cell of the lattice (t < Tb, u <= Ub).  All six loads are unconditional — the neighbours' indices are clamped
+  // to the cell itself where the lattice ends and the value is dropped by a select — so a caller that builds several cells per thread
+  // gets its loads issued back to back instead of one dependent round trip per `if`.
   CellS c;
   const long o = rowbase + (long)u * T + t;
+  const bool last_t = t == Tb - 1, has_label = u < Ub;
   const double a = alpha[o], bt = beta[o];
-  const float lb = blk[o];
+  const double b_next_t = beta[last_t ? o : o + 1], b_next_u = beta[has_label ? o + T : o];
+  const float lb = blk[o], le = emit[o];
   c.w = expf((float)(a + bt - logZ));
   c.lse = zblank - lb;
-  double tb;
-  if (t == Tb - 1) tb = (u == Ub) ? a + (double)lb - logZ : NEG_INF;
-  else tb = a + (double)lb + beta[o + 1] - logZ;
+  const double tb = last_t ? ((u == Ub) ? a + (double)lb - logZ : NEG_INF) : a + (double)lb + b_next_t - logZ;
   c.cb = expf((float)tb);
-  c.ce = (u < Ub) ? expf((float)(a + (double)emit[o] + beta[o + T] - logZ)) : 0.f;
+  c.ce = has_label ? expf((float)(a + (double)le + b_next_u - logZ)) : 0.f;
   return c;
 }
 
@@ -549,17 +552,31 @@ __global__ void __launch_bounds__(64 * NW, 3) grad_sepv_kernel(const float* __re
   const int nf = max(0, min(TT, Tb - t0));            // valid frames of this tile (uniform)
 
   for (int i = tid; i < U1; i += 64 * NW) ys[i] = (i < U1 - 1) ? labels[(long)b * (U1 - 1) + i] : -1;
-  for (int i = tid; i < TT * U1; i += 64 * NW) {
-    const int u = i / TT, tl = i % TT, t = t0 + tl;   // consecutive threads -> consecutive frames: alpha / beta / blk / emit rows are read coalesced
-    CellS c = {0.f, 0.f, 0.f, 0.f};
-    if (t < Tb && u <= Ub) {
-      const float zb = Ab[(long)t * a_st + blank] + Cb[(long)u * c_su + blank] + bias[blank];
-      c = cell_scalars(blk, emit, alpha, beta, rowbase, T, t, u, Tb, Ub, logZ, zb);
+  // the cell table: four cells per thread and round, every load unconditional (indices clamped into the lattice, results dropped by
+  // selects) so that the 4 x 8 loads of a round are in flight together; consecutive threads -> consecutive frames (coalesced rows)
+  const float bias_blank = bias[blank];
+  for (int i0 = tid; i0 < TT * U1; i0 += 64 * NW * 4) {
+    CellS c[4];
+    bool in[4];
+    int dst[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q * 64 * NW;
+      const int u = min(i / TT, U1 - 1), tl = i % TT, t = t0 + tl;
+      in[q] = i < TT * U1 && t < Tb && u <= Ub;
+      dst[q] = i < TT * U1 ? tl * U1 + u : -1;
+      const int tc = min(t, Tb - 1), uc = min(u, Ub);   // a cell of the lattice whatever (t, u) is
+      const float zb = Ab[(long)tc * a_st + blank] + Cb[(long)uc * c_su + blank] + bias_blank;
+      c[q] = cell_scalars(blk, emit, alpha, beta, rowbase, T, tc, uc, Tb, Ub, logZ, zb);
     }
-    // cells outside the utterance's lattice: w = 0 and an lse that sends 2^(x - lse) to 0, so the inner loop needs no per-cell test
-    const bool in = t < Tb && u <= Ub;
-    wl[tl * U1 + u] = make_float2(c.w, in ? c.lse * LOG2E_F : 1e30f);
-    cbe[tl * U1 + u] = make_float2(c.cb, c.ce);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (dst[q] >= 0) {
+        // cells outside the utterance's lattice: w = 0 and an lse that sends 2^(x - lse) to 0, so the inner loop needs no per-cell test
+        wl[dst[q]] = in[q] ? make_float2(c[q].w, c[q].lse * LOG2E_F) : make_float2(0.f, 1e30f);
+        cbe[dst[q]] = in[q] ? make_float2(c[q].cb, c[q].ce) : make_float2(0.f, 0.f);
+      }
+    }
   }
   __syncthreads();
   if (vw0 >= V) return;   // (whole wave beyond the vocabulary: nothing to do, and no barrier follows)
