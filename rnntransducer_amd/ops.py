@@ -129,7 +129,7 @@ class HpTensor:
         self.rows, self.K = int(rows), int(K)
         n = _lib.lib().rnnt_hip_hp_bytes(self.rows, self.K)
         self.planes = torch.empty(max(n, 128), device=device, dtype=torch.uint8)
-        self.amax = torch.zeros(max(self.rows, 1), device=device, dtype=torch.int32)   # per-row maxima (fp32 bit patterns)
+        self.amax = torch.empty(max(self.rows, 1), device=device, dtype=torch.int32)   # per-row maxima (fp32 bit patterns), written by the split
 
 
 def hp_split(x: torch.Tensor, transpose: bool = False, shift: int = 0, K: Optional[int] = None) -> HpTensor:

@@ -5,7 +5,7 @@
 #   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...          -> matrix-core utilisation per kernel
 # The program itself follows `--` (python3 bench.py ...): no env / bash -c hop under the profiler.
 set -o pipefail
-CFG=${1:-c2}; TAG=${2:-r02}
+CFG=${1:-c2}; TAG=${2:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_prof_${CFG}
 mkdir -p $OUT
