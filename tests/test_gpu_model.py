@@ -81,6 +81,52 @@ def test_config1_synthetic_vs_oracle_train_step():
         assert (p.grad.double().cpu() - q.grad).abs().max().item() < 2e-4 * scale, name
 
 
+def test_ragged_batch_in_collate_order_takes_the_valid_frame_plan_and_matches_the_oracle(monkeypatch):
+    """A ragged batch in COLLATE order (not sorted) through `training_step`-style calls with the host list of lengths: the module
+    sorts the rows by length (networks/encoder.py:94-96), the recurrences / big products skip the padding (ops.RaggedPlan), and the
+    per-utterance NLL comes back in the caller's order.  Every utterance's NLL and every parameter gradient against the float64
+    oracle; and the same numbers as the dense path (no host list).  RNNT_GEMM_FORCE_HP puts this small shape on the half-pair
+    products, where the valid-frame table is honoured."""
+    from argparse import Namespace
+    from oracle.rnnt_oracle import OracleJointNet, make_batch, training_loss
+    from rnntransducer_amd import RNNTransducer, _lib
+    monkeypatch.setenv("RNNT_GEMM_FORCE_HP", "1")
+    V, B, T, U = 40, 6, 200, 12
+    tn = dict(input_size=80, hidden_size=128, output_size=64, num_layers=2, rnn_type="lstm", dropout=0.0, bidirectional=True)
+    pn = dict(embedding_size=V, hidden_size=64, output_size=64, num_layers=1, rnn_type="lstm", dropout=0.0)
+    assert _lib.lib().rnnt_hip_lstm_takes_row_idx(T, B, 80, 128, 2, 0) == 1
+    args = Namespace(learning_rate=1e-3, weight_decay=1e-4, warmup_ratio=0.2, final_div_factor=1e4, total_steps=10, move_metrics_to_cpu=False)
+    torch.manual_seed(5)
+    model = RNNTransducer(dict(pn), dict(tn), dict(num_classes=V), args)
+    oracle = OracleJointNet(dict(tn), dict(pn, pad_token_id=0), V).double()
+    oracle.load_state_dict({k[len("jointnet."):]: v.double() for k, v in model.state_dict().items()})
+    batch = list(make_batch(B, T, U, V, ragged=True, seed=21))
+    lens = [T, 117, 180, 101, 199, 150]                     # collate order: unsorted, every row different
+    for b in range(B):
+        batch[0][b, lens[b]:] = 0
+    batch[1], batch[2] = lens, torch.tensor(lens, dtype=torch.int32)
+    gw = torch.tensor([1.0, 0.5, 2.0, 1.5, 0.25, 1.0], dtype=torch.float64)   # a different weight per utterance: order matters
+    from oracle.rnnt_oracle import _RNNTLossFn
+    logits = oracle(batch[0].double(), batch[1], batch[3], batch[4])
+    ref_nll = _RNNTLossFn.apply(logits, batch[5], batch[2], batch[6], 0)
+    (ref_nll * gw).sum().backward()
+    model = model.cuda().train()
+    dev = tuple(x.cuda() if isinstance(x, torch.Tensor) else x for x in batch)
+    res = {}
+    for name, host_list in (("plan", dev[1]), ("dense", None)):
+        for p in model.parameters():
+            p.grad = None
+        nll = model.jointnet.loss(dev[0], dev[2], dev[3], dev[5], dev[6], 0, reduction="none", audio_lengths=host_list)
+        (nll * gw.float().cuda()).sum().backward()
+        torch.cuda.synchronize()
+        res[name] = (nll.detach().double().cpu(), {k: p.grad.double().cpu() for k, p in model.jointnet.named_parameters()})
+        assert torch.allclose(res[name][0], ref_nll.detach(), rtol=1e-5, atol=0), (name, res[name][0], ref_nll)
+        for k, q in oracle.named_parameters():
+            scale = max(q.grad.abs().max().item(), 1e-2)
+            assert (res[name][1][k] - q.grad).abs().max().item() < 2e-4 * scale, (name, k)
+    assert torch.allclose(res["plan"][0], res["dense"][0], rtol=2e-6, atol=0)
+
+
 def test_fused_step_never_materialises_btuv():
     """config-3-shaped (scaled to fit a quick test): peak memory of the fused step stays far below one (B,T,U+1,V)
     tensor plus one (B,T,U+1,2*O) tensor, which the reference allocates at networks/transducer.py:61-69."""
