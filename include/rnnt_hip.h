@@ -255,7 +255,8 @@ int rnnt_hip_lstm_bwd(const rnnt_lstm_bwd_desc* d, void* stream);
 /* reads back the persistent kernels' status word from a workspace (synchronises `stream`);
  * 0 = ok, RNNT_ERR_TIMEOUT if an inter-CU wait gave up.  For tests and the bench, not for hot loops. */
 int rnnt_hip_lstm_check(const void* workspace, void* stream);
-/* Diagnostics: with RNNT_LSTM_DBG set in the environment the v2 recurrences accumulate shader-clock cycles per step
+/* Diagnostics (a library built with -DRNNT_LSTM_DBG_STAMPS=1 only: the stamps are compiled out of the default build, where this
+ * entry returns zeros): with RNNT_LSTM_DBG set in the environment the recurrences accumulate shader-clock cycles per step
  * phase (0 prefetch issue, 1 flag wait, 2 gather+MFMA, 3 reduce+cell math, 4 drain+barrier+flag, 5 stash stores) for
  * lane 0 of every workgroup; this copies the last launch's table (nwg x 8 u64) to host memory (synchronises). */
 int rnnt_hip_lstm_debug_read(const void* workspace, int32_t T, int32_t B, int32_t I, int32_t H, int32_t D,

@@ -66,7 +66,16 @@ constexpr int AUX_SC1 = 16;
 
 
 
+// Per-phase cycle stamps of the step loops: compiled in only with -DRNNT_LSTM_DBG_STAMPS=1 (tools/lstm_phase_probe.py builds that
+// variant: `python -m rnntransducer_amd.csrc.build --variant dbg --only=lstm.hip,lstm5.hip -DRNNT_LSTM_DBG_STAMPS=1`).  Even with
+// p.dbg == nullptr the six `if (p.dbg && tid == 0)` tests per step cost the latency-bound loops 4.5 % (forward) / 3.5 % (backward) of
+// their time at config 2 (paired runs: 6.08 -> 5.81 and 7.43 -> 7.17 ms per training step): the step is instruction-issue-bound in the
+// gathering waves, not only exchange-latency-bound.
+#ifdef RNNT_LSTM_DBG_STAMPS
 #define DBG_STAMP(i) do { if (p.dbg && tid == 0) { const unsigned long long now_ = clock64(); dsum[i] += now_ - dlast; dlast = now_; } } while (0)
+#else
+#define DBG_STAMP(i) do { } while (0)
+#endif
 
 // counter-based dropout mask: murmur3-style 32-bit finaliser of (seed, element index) -- a dozen 32-bit ops, the
 // forward and backward kernels regenerate the same mask from the same (seed, index)

@@ -1,8 +1,15 @@
 """Diagnostic: per-phase cycle shares of one step of the persistent LSTM recurrences (v5 by default; RNNT_LSTM_NO_V5=1: v3/v4) at BASELINE config 2 layer shapes.
-   RNNT_LSTM_DBG=1 python tools/lstm_phase_probe.py"""
+   The per-phase stamps are compiled out of the default library (they cost the step loops 3.5-4.5 %): build the variant first, in the container,
+   python -m rnntransducer_amd.csrc.build --variant dbg --only=lstm.hip,lstm5.hip -DRNNT_LSTM_DBG_STAMPS=1
+   and run this script on the GPU box; it loads librnnt_hip_dbg.so by itself."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RNNT_LSTM_DBG"] = "1"
+_dbg_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rnntransducer_amd", "csrc", "librnnt_hip_dbg.so")
+if not os.environ.get("RNNT_HIP_LIB"):
+    if not os.path.exists(_dbg_lib):
+        raise SystemExit("build the stamped variant first: python -m rnntransducer_amd.csrc.build --variant dbg --only=lstm.hip,lstm5.hip -DRNNT_LSTM_DBG_STAMPS=1")
+    os.environ["RNNT_HIP_LIB"] = _dbg_lib
 import numpy as np
 import torch
 from rnntransducer_amd import _lib
