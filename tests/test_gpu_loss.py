@@ -29,6 +29,16 @@ def test_g3_known_answer_on_gpu():
     np.testing.assert_allclose(grad, G3_GRAD, atol=1e-6)
 
 
+def test_second_upstream_known_answer_vector_on_gpu():
+    """The B=2, T=4, U=2, V=3 known-answer vector of warp-transducer's / torchaudio's own loss tests (tests/test_oracle_loss.py: expected
+    costs 4.28065286 / 3.93843698) through the HIP lattice kernels; gradients against the float64 restatement."""
+    from tests.test_oracle_loss import KAT2_ACTS, KAT2_COSTS, KAT2_LABELS
+    nll, grad = _run_dense(KAT2_ACTS, KAT2_LABELS, [4, 4], [2, 2])
+    np.testing.assert_allclose(nll, KAT2_COSTS, atol=5e-6)
+    _, ref_grad = rnnt_loss_c(KAT2_ACTS.astype(np.float64), KAT2_LABELS, [4, 4], [2, 2], 0)
+    np.testing.assert_allclose(grad, ref_grad, atol=1e-6)
+
+
 @pytest.mark.parametrize("B,T,U,V,blank,ragged", [(1, 1, 0, 3, 0, False), (2, 1, 3, 5, 0, False), (3, 7, 0, 4, 1, True),
                                                   (4, 50, 20, 72, 0, True), (2, 33, 70, 9, 3, True),
                                                   (2, 20, 150, 6, 0, True), (3, 40, 300, 5, 0, True),

@@ -26,6 +26,29 @@ def test_g3_known_answer(dtype, tol):
     np.testing.assert_allclose(grad, G3_GRAD, atol=tol)
 
 
+# Second upstream known-answer vector [upstream, recalled]: the B=2, T=4, U=2, V=3 case of warp-transducer's / torchaudio's RNN-T loss tests
+# (labels [[1,2],[1,1]] — a repeated label —, blank 0, expected costs 4.2806528590890736 and 3.9384369822503591).  The 72 inputs are
+# written from memory of the upstream test; the expected costs are an 8-digit checksum of them: a single wrong input digit moves a
+# cost by ~1e-6 or more, so the vector validates itself together with the restatement.
+KAT2_ACTS = np.array([0.065357, 0.787530, 0.081592, 0.529716, 0.750675, 0.754135, 0.609764, 0.868140, 0.622532, 0.668522, 0.858039, 0.164539,
+                      0.989780, 0.944298, 0.603168, 0.946783, 0.666203, 0.286882, 0.094184, 0.366674, 0.736168, 0.166680, 0.714154, 0.399400,
+                      0.535982, 0.291821, 0.612642, 0.324241, 0.800764, 0.524106, 0.779195, 0.183314, 0.113745, 0.240222, 0.339470, 0.134160,
+                      0.505562, 0.051597, 0.640290, 0.430733, 0.829473, 0.177467, 0.320700, 0.042883, 0.302803, 0.675178, 0.569537, 0.558474,
+                      0.083132, 0.060165, 0.107958, 0.748615, 0.943918, 0.486356, 0.418199, 0.652408, 0.024243, 0.134582, 0.366342, 0.295830,
+                      0.923670, 0.689929, 0.741898, 0.250005, 0.603430, 0.987289, 0.592606, 0.884672, 0.543450, 0.660770, 0.377128, 0.358021]
+                     ).reshape(2, 4, 3, 3)
+KAT2_LABELS, KAT2_COSTS = np.array([[1, 2], [1, 1]]), np.array([4.2806528590890736, 3.9384369822503591])
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 5e-7), (np.float32, 2e-6)])
+def test_second_upstream_known_answer_vector_batch_of_two(dtype, tol):
+    nll, grad = rnnt_loss_c(KAT2_ACTS.astype(dtype), KAT2_LABELS, [4, 4], [2, 2], blank=0)
+    np.testing.assert_allclose(nll, KAT2_COSTS, atol=tol)
+    np.testing.assert_allclose(grad.sum(-1), 0, atol=1e-6)   # softmax-fused gradients sum to zero over the vocabulary
+    for b in range(2):   # and the restatement agrees with the path enumeration on it
+        assert abs(float(nll[b]) - rnnt_nll_bruteforce(KAT2_ACTS[b].astype(np.float64), list(KAT2_LABELS[b]), 0)) < (1e-9 if dtype == np.float64 else 2e-6)
+
+
 @pytest.mark.parametrize("T,U,V,seed", [(1, 0, 3, 0), (1, 3, 4, 1), (4, 0, 5, 2), (2, 2, 5, 3), (5, 4, 6, 4), (3, 3, 2, 5)])
 def test_g4_bruteforce(T, U, V, seed):
     rng = np.random.default_rng(seed)
