@@ -17,7 +17,7 @@
  *
  * PARITY PIN: the reference holds no test or golden vector for this boundary.
  * This file is pinned by (tests/test_oracle_loss.py): the upstream 2x3x5 known-answer vector G3
- * (NLL 4.495666 and its 30 gradient entries), brute-force enumeration of all monotone lattice paths,
+ * (NLL 4.495666 and its 30 gradient entries), the upstream B=2 x T=4 x U=2 x V=3 vector (costs 4.28065286 / 3.93843698), brute-force enumeration of all monotone lattice paths,
  * and torch-autograd through an independent float64 DP.  It is NOT pinned by running the reference's
  * own loss package: that part of parity is "unpinned by the reference".
  *
