@@ -152,6 +152,45 @@ def test_ragged_plan_skips_padding_without_changing_results(B, T, I, H, L, bi, c
             close(name, gr_p[name], q.grad)
 
 
+@pytest.mark.parametrize("B,T,lens", [
+    (1, 1100, [700]),                                  # one utterance shorter than the padded length
+    (9, 130, [130, 1, 1, 1, 64, 1, 129, 2, 1]),        # one-frame rows (the reverse direction starts AND ends at frame 0), 9 rows = 3 groups
+    (4, 300, [1, 1, 1, 300]),                          # fewer valid rows than one 256-row GEMM tile apart from a single long row
+    (70, 16, [16] * 35 + [3] * 35),                    # B above the per-launch limit: the module slices the batch and runs the slices dense
+])
+def test_ragged_plan_edge_cases(B, T, lens, monkeypatch):
+    """Valid-frame table at the edges (RNNT_GEMM_FORCE_HP puts these small shapes on the half-pair products, where the table is
+    honoured): outputs and every gradient against torch float64."""
+    from rnntransducer_amd.networks.rnn import HipLSTM
+    from rnntransducer_amd.ops import RaggedPlan
+    monkeypatch.setenv("RNNT_GEMM_FORCE_HP", "1")
+    I, H = 64, 128
+    torch.manual_seed(B * 7 + T)
+    ref = nn.LSTM(I, H, 2, batch_first=True, bidirectional=True).double()
+    hip = HipLSTM(I, H, 2, dropout=0.0, bidirectional=True)
+    hip.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hip = hip.cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, I, generator=g)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    dy = torch.randn(B, T, 2 * H, generator=g)
+    ref_out, ref_dx = _oracle(x, lens, ref, dy)
+    x_tm = x.transpose(0, 1).contiguous().cuda().requires_grad_(True)
+    y = hip(x_tm, RaggedPlan(lens, T, "cuda"))
+    y.backward(dy.transpose(0, 1).contiguous().cuda())
+    torch.cuda.synchronize()
+    assert (y.detach().transpose(0, 1).double().cpu() - ref_out).abs().max().item() < FWD_ATOL
+    dx = x_tm.grad.transpose(0, 1).clone()
+    for b in range(B):
+        assert torch.all(y[lens[b]:, b] == 0)
+        dx[b, lens[b]:] = 0
+    for name, got, want in [("dx", dx, ref_dx)] + [(k, getattr(hip, k).grad, p.grad) for k, p in ref.named_parameters()]:
+        scale = max(want.abs().max().item(), 1e-3)
+        e = (got.double().cpu() - want).abs().max().item()
+        assert e < GRAD_RTOL * scale + 1e-6, f"{name}: err {e} scale {scale}"
+
+
 def test_lstm_init_matches_torch_rng_stream():
     from rnntransducer_amd.networks.rnn import HipLSTM
     torch.manual_seed(7)
