@@ -318,3 +318,35 @@ def test_cpu_build_of_the_same_abi_agrees_with_the_hip_library():
     # the same bad-argument convention on both sides
     assert cpu.rnnt_hip_loss_from_logits_fwd_bwd(None, None, None, None, 1, 1, 1, 3, 0, ctypes.c_float(1.0), None, None, None, 0, None) == -1
     assert hip.rnnt_hip_loss_from_logits_fwd_bwd(None, None, None, None, 1, 1, 1, 3, 0, ctypes.c_float(1.0), None, None, None, 0, None) == -1
+
+
+def test_training_step_under_fp16_autocast_and_grad_scaler_is_the_fp32_step():
+    """scripts/run_train.sh:32 launches the reference with `--precision 16`: Lightning then wraps training_step in
+    torch.autocast(float16) and drives a GradScaler (model.py:28-31 picks torchaudio's loss for that mode).  This module computes in
+    fp32 whatever the autocast state says — its kernels are not torch ops autocast could down-cast, which is at least the reference's
+    precision — so the drop-in must (a) run unchanged inside the autocast region, (b) survive the scaler's loss scaling / unscaling /
+    inf check on the flat gradient views, and (c) take the same optimizer step as the plain fp32 loop."""
+    batch = _batch(seed=8)
+    models, opts = [], []
+    for _ in range(2):
+        m = _small_model(_args(), seed=6, dropout=0.0)
+        models.append(m)
+        opts.append(m.configure_optimizers()["optimizer"])
+    plain, amp = models
+    opts[0].zero_grad()
+    l0 = plain.training_step(batch, 0)["loss"]
+    l0.backward()
+    opts[0].step()
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 14)
+    opts[1].zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        l1 = amp.training_step(batch, 0)["loss"]
+    assert l1.dtype == torch.float32 and torch.equal(l1, l0)
+    scaler.scale(l1).backward()
+    scaler.step(opts[1])          # unscales the .grad views in place, checks them for inf / nan, then calls FlatAdamW.step()
+    scaler.update()
+    torch.cuda.synchronize()
+    assert scaler.get_scale() == 2.0 ** 14   # no overflow was found
+    for (n, a), (_, b) in zip(plain.named_parameters(), amp.named_parameters()):
+        # power-of-two loss scale: the scaled gradients are exact multiples, so the update is the same up to the unscale rounding
+        assert torch.allclose(a, b, rtol=0, atol=2e-7), n
