@@ -751,6 +751,7 @@ int check_common(const void* labels, const void* t_lens, const void* u_lens, int
   RNNT_CHECK_ARG(B >= 1 && T >= 1 && U1 >= 1 && V >= 1, "rnnt loss: dims must be positive (B=%d T=%d U1=%d V=%d)", B, T, U1, V);
   RNNT_CHECK_ARG(blank >= 0 && blank < V, "rnnt loss: blank %d outside [0,%d)", blank, V);
   RNNT_CHECK_ARG(U1 <= 64 * 8, "rnnt loss: U+1 = %d exceeds the 512 label positions one wavefront sweeps", U1);
+  RNNT_CHECK_ARG((int64_t)U1 * T * 8 < (1ll << 31), "rnnt loss: one utterance's lattice (T = %d x U+1 = %d, fp64) exceeds the 2 GB a buffer resource addresses", T, U1);
   RNNT_CHECK_ARG(t_lens && u_lens && nll, "rnnt loss: null lengths/output");
   RNNT_CHECK_ARG(U1 == 1 || labels, "rnnt loss: null labels");
   return RNNT_OK;
