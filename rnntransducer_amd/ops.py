@@ -171,9 +171,11 @@ def gemm_hp(a: HpTensor, b: HpTensor, out: Optional[torch.Tensor] = None, bias: 
     return out
 
 
-def gemm_hp_grouped(pairs, outs=None, accumulate: bool = False, xcd_skip: int = 0):
+def gemm_hp_grouped(pairs, outs=None, accumulate: bool = False, xcd_skip: int = 0, check: bool = False):
     """[C_i (M_i, N_i) [+]= A_i . B_i^T] for up to 4 (A, B) pairs of hp operands in ONE queue-driven launch; `xcd_skip`: bit mask of
-    XCDs whose workgroups leave at once (the launch then runs on the other XCDs only)."""
+    XCDs whose workgroups leave at once (the launch then runs on the other XCDs only).  `check`: read back (synchronising) the
+    launch's self-check — word 9 of the workspace is 1 when units were left undone because the mask named XCDs the device does not
+    expose (include/rnnt_hip.h) — and raise RnntHipError in that case."""
     n = len(pairs)
     if not 1 <= n <= 4:
         raise ValueError("1..4 products per grouped launch")
@@ -191,7 +193,12 @@ def gemm_hp_grouped(pairs, outs=None, accumulate: bool = False, xcd_skip: int = 
         res.append(out)
     nws = _lib.lib().rnnt_hip_gemm_hp_grouped_workspace_bytes(pr, n)
     ws = torch.empty(nws, device=res[0].device, dtype=torch.uint8)
-    check(_lib.lib().rnnt_hip_gemm_hp_grouped(pr, n, int(xcd_skip), _addr(ws), nws, _stream()), "rnnt_hip_gemm_hp_grouped")
+    _lib.check(_lib.lib().rnnt_hip_gemm_hp_grouped(pr, n, int(xcd_skip), _addr(ws), nws, _stream()), "rnnt_hip_gemm_hp_grouped")
+    if check:
+        words = ws[:64].view(torch.int32).tolist()
+        if words[9] != 0:
+            raise RnntHipError(f"grouped half-pair GEMM left units undone ({words[8]} drawn): xcd_skip = {xcd_skip:#x} names XCDs this "
+                               "device does not expose")
     return res
 
 

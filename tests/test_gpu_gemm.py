@@ -269,7 +269,7 @@ def test_gemm_hp_grouped_queue_launch(xcd_skip):
     mats = [(torch.randn(Kc, m, generator=g) * torch.exp(torch.empty(Kc, 1).uniform_(-8, 0, generator=g)), torch.randn(Kc, n, generator=g))
             for m, n in shapes]
     pairs = [(hp_split(a.cuda(), transpose=True), hp_split(b.cuda(), transpose=True)) for a, b in mats]
-    outs = gemm_hp_grouped(pairs, xcd_skip=xcd_skip)
+    outs = gemm_hp_grouped(pairs, xcd_skip=xcd_skip, check=True)   # check: the launch's own "every unit was drawn" word is clean
     again = gemm_hp_grouped(pairs, xcd_skip=xcd_skip)
     base = [torch.randn(m, n, generator=g) for m, n in shapes]
     acc = gemm_hp_grouped(pairs, outs=[b.clone().cuda() for b in base], accumulate=True, xcd_skip=xcd_skip)
