@@ -209,7 +209,9 @@ def launch_ranks(a, argv):
     `python -m torch.distributed.run` on 127.0.0.1 (what scripts/run_train.sh:7-9 of the reference does with torchrun), lets their
     stdout / stderr through (rank 0 prints the JSON line) and exits with the ranks' return code."""
     import subprocess
-    if not a.stub:
+    if a.share_gpu and a.backend != "gloo":
+        raise SystemExit("--share-gpu needs --backend gloo (RCCL does not take two ranks on one device)")
+    if not a.stub and not a.share_gpu:
         ndev = torch.cuda.device_count()
         if ndev < a.gpus:
             raise SystemExit(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) are visible; refusing to measure fewer devices than asked")
@@ -298,6 +300,12 @@ def main():
     ap.add_argument("--stub", action="store_true",
                     help="tests only: run the launcher / sharding / timing plumbing on the CPU (gloo) with the step replaced by a "
                          "sleep; prints metric 'stub', never a measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N > 1 path (nccl = RCCL over xGMI: the measured configuration; gloo: rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (with --backend gloo), so the N > 1 code path — model step, flat all-reduce "
+                         "with the status slot, barrier, max-over-ranks timing — runs end to end on a one-GPU box; the line says so and is "
+                         "not a measurement of N GPUs")
     a = ap.parse_args()
 
     if a.gpus < 1:
@@ -314,12 +322,17 @@ def main():
         return run_stub(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists in rnntransducer_amd)")
+    if a.share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from rnntransducer_amd import _lib
     from rnntransducer_amd.data import synthetic_batch
@@ -490,6 +503,9 @@ def main():
     if dt_unprof is not None:
         out["ms_per_step_unprofiled"] = round(1e3 * dt_unprof, 3)
     out["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
+    if world > 1 and (a.backend != "nccl" or a.share_gpu):
+        out["rehearsal"] = f"backend {a.backend}, {'all ranks on cuda:0' if a.share_gpu else 'one GPU per rank'}: NOT a measurement of {world} GPUs over RCCL"
+        out["metric"] = "utterances/sec (rehearsal of the N > 1 path, not a multi-GPU measurement)"
     parity_ok = True
     if rank == 0:
         progress(f"timed region done: {out['value']} utt/s, {out['ms_per_step']} ms per step")
