@@ -356,8 +356,18 @@ def main():
 
     def step():
         opt.zero_grad()
-        loss = model.training_step(batch, 0)["loss"]
-        loss.backward()
+        if a.share_gpu and world > 1:
+            # rehearsal on one device: the ranks take turns for forward + backward (two processes' persistent recurrences cannot be
+            # co-resident on one GPU); everything after it — the exchange, the guarded update — is the N > 1 path as it ships
+            for turn in range(world):
+                if turn == rank:
+                    loss = model.training_step(batch, 0)["loss"]
+                    loss.backward()
+                    torch.cuda.synchronize()
+                dist.barrier()
+        else:
+            loss = model.training_step(batch, 0)["loss"]
+            loss.backward()
         opt.all_reduce_grads()
         opt.step()
         sched.step()
