@@ -91,8 +91,11 @@ def test_ragged_plan_skips_padding_without_changing_results(B, T, I, H, L, bi, c
     torch.manual_seed(B + T + H)
     D = 2 if bi else 1
     cell_id = RNN_CELLS[cell].CELL if cell != "rnn" else 2
-    assert _lib.lib().rnnt_hip_lstm_takes_row_idx(T, B, I, H, D, cell_id) == 1   # the table is honoured at this shape, not ignored
-    assert _lib.lib().rnnt_hip_lstm_takes_row_idx(7, 3, 8, 16, D, cell_id) == 0     # (small shapes ignore it and stay dense)
+    import os
+    if not any(os.environ.get(k) for k in ("RNNT_LSTM_NO_V5", "RNNT_GEMM_NO_HP", "RNNT_LSTM_V1", "RNNT_LSTM_V2", "RNNT_LSTM_EXACT_MATH")):
+        assert _lib.lib().rnnt_hip_lstm_takes_row_idx(T, B, I, H, D, cell_id) == 1   # the table is honoured at this shape, not ignored
+    # (under the fallback switches the library ignores the table and computes all rows: the results below must hold either way)
+    assert _lib.lib().rnnt_hip_lstm_takes_row_idx(7, 3, 8, 16, D, cell_id) == 0     # small shapes ignore it and stay dense
     ref_cls = {"lstm": nn.LSTM, "gru": nn.GRU, "rnn": nn.RNN}[cell]
     ref = ref_cls(I, H, L, batch_first=True, bidirectional=bi).double()
     hip = RNN_CELLS[cell](I, H, L, dropout=p, bidirectional=bi)

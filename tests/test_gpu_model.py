@@ -94,7 +94,9 @@ def test_ragged_batch_in_collate_order_takes_the_valid_frame_plan_and_matches_th
     V, B, T, U = 40, 6, 200, 12
     tn = dict(input_size=80, hidden_size=128, output_size=64, num_layers=2, rnn_type="lstm", dropout=0.0, bidirectional=True)
     pn = dict(embedding_size=V, hidden_size=64, output_size=64, num_layers=1, rnn_type="lstm", dropout=0.0)
-    assert _lib.lib().rnnt_hip_lstm_takes_row_idx(T, B, 80, 128, 2, 0) == 1
+    import os
+    if not any(os.environ.get(k) for k in ("RNNT_LSTM_NO_V5", "RNNT_GEMM_NO_HP", "RNNT_LSTM_V1", "RNNT_LSTM_V2", "RNNT_LSTM_EXACT_MATH")):
+        assert _lib.lib().rnnt_hip_lstm_takes_row_idx(T, B, 80, 128, 2, 0) == 1
     args = Namespace(learning_rate=1e-3, weight_decay=1e-4, warmup_ratio=0.2, final_div_factor=1e4, total_steps=10, move_metrics_to_cpu=False)
     torch.manual_seed(5)
     model = RNNTransducer(dict(pn), dict(tn), dict(num_classes=V), args)
